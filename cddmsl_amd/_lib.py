@@ -1,0 +1,59 @@
+"""ctypes binding of the C-ABI HIP library (``libcddmsl_hip.so``, declared in ``include/cddmsl_hip.h``).
+
+The library is the product: every hot-path op of the package goes through it.  There is no CPU
+or eager-PyTorch fallback -- if the shared object is missing, or a call returns a non-zero
+status, this module raises.  PyTorch only supplies device memory (``Tensor.data_ptr()``) and the
+stream handle the kernels are enqueued on.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcddmsl_hip.so")
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Return the loaded library, loading it on first use.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  cddmsl_amd has no fallback path."
+            )
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def stream_ptr():
+    """The HIP stream torch is currently enqueuing on, as a void*."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL for None)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check(status, what):
+    if status != 0:
+        raise HipLibraryError(f"{what} failed with status {status}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipLibraryError(
+                "cddmsl_amd ops run only on the MI355X HIP path; got a CPU tensor "
+                "(the CPU restatement lives in oracle/ and is test infrastructure only)"
+            )

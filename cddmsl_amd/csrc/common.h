@@ -1,0 +1,45 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the CDDMSL hot path.
+// Wavefront = 64 lanes everywhere; no CUDA-compat paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CDDMSL_OK 0
+#define CDDMSL_ERR_ARG 1
+#define CDDMSL_ERR_LAUNCH 2
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((ext_vector_type(8))) short i16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// f32 -> bf16 bits, round-to-nearest-even; plain cast keeps NaN a NaN (v_cvt_pk_bf16_f32).
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) {
+  return __builtin_bit_cast(float, ((unsigned int)u) << 16);
+}
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CDDMSL_OK : CDDMSL_ERR_LAUNCH;
+}
