@@ -1,0 +1,182 @@
+"""CPU: pins the oracle (oracle/) against (a) the known-answer tables the reference's own tests hold
+(tests/golden/kat.json) and (b) golden vectors produced by the reference's own leaf modules
+(tests/golden/ref_*.npz, generator: tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cddmsl_amd import synthetic
+from oracle import model as om
+from oracle import ops as oo
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+KAT = json.load(open(os.path.join(G, "kat.json")))
+T = torch.tensor
+
+
+def _npz(name):
+    return np.load(os.path.join(G, name))
+
+
+def seeded(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synthetic.make_state_dict(0)
+
+
+# ------------------------------------------------------------------ known-answer tables
+@pytest.mark.parametrize("aligned", [False, True])
+def test_kat_roi_align(aligned):
+    k = KAT["roi_align_5x5"]
+    x = torch.arange(25, dtype=torch.float32).reshape(1, 1, 5, 5)
+    rois = T([[0.0] + [float(v) for v in k["box"]]])
+    out = oo.roi_align(x, rois, tuple(k["output_size"]), 1.0, 0, aligned)
+    exp = T(k["aligned_true" if aligned else "aligned_false"])
+    assert torch.allclose(out[0, 0], exp)
+
+
+def test_kat_roi_align_empty():
+    # tests/layers/test_roi_align.py:111-128: empty box -> zeros, zero grad; empty batch -> shape (0,C,h,w)
+    x = torch.rand(1, 3, 5, 5, requires_grad=True)
+    out = oo.roi_align(x, T([[0.0, 3.0, 3.0, 3.0, 3.0]]), 7, 1.0, 0, True)
+    assert out.shape == (1, 3, 7, 7) and (out == 0).all()
+    out.sum().backward()
+    assert (x.grad == 0).all()
+    assert oo.roi_align(x, torch.zeros(0, 5), 7, 1.0, 0, True).shape == (0, 3, 7, 7)
+
+
+def test_kat_matcher():
+    k = KAT["matcher"]
+    m, l = oo.matcher(T(k["quality"]), k["thresholds"], k["labels"], k["allow_low_quality"])
+    assert m.tolist() == k["matches"] and l.tolist() == k["match_labels"] and l.dtype == torch.int8
+
+
+def test_kat_pairwise_iou():
+    k = KAT["pairwise_iou"]
+    iou = oo.pairwise_iou(T(k["boxes1"]), T(k["boxes2"]))
+    assert torch.allclose(iou, T([k["iou_row"], k["iou_row"]]))
+
+
+def test_kat_anchors():
+    k = KAT["anchors"]
+    a = oo.grid_anchors(k["grid"][0], k["grid"][1], k["stride"], k["offset"], k["sizes"], k["ratios"])
+    assert torch.allclose(a, T(k["expected"]))
+
+
+def test_kat_scheduler():
+    k = KAT["scheduler"]
+    cfg = om.Cfg(base_lr=k["base_lr"], steps=tuple(k["steps"]), gamma=k["gamma"], warmup_factor=k["warmup_factor"],
+                 warmup_iters=k["warmup_iters"], max_iter=k["max_iter"])
+    lrs = [om.lr_at(cfg, i) for i in range(31)]
+    assert np.allclose(lrs[:5], k["lrs_0_5"])
+    assert np.allclose(lrs[5:10], k["lr_5_10"]) and np.allclose(lrs[10:15], k["lr_10_15"])
+    assert np.allclose(lrs[15:20], k["lr_15_20"]) and np.allclose(lrs[20:], k["lr_20_30"])
+
+
+# ------------------------------------------------------------------ reference leaf-module goldens
+def test_ref_backbone(sd):
+    g = _npz("ref_backbone.npz")
+    cfg = om.Cfg()
+    with torch.no_grad():
+        o = om.backbone(sd, cfg, seeded((2, 3, 64, 96), 11))
+        assert np.allclose(o["res4"].numpy(), g["res4_64x96"], rtol=1e-4, atol=1e-5)
+        assert np.allclose(o["res5"].numpy(), g["res5_64x96"], rtol=1e-4, atol=1e-5)
+        o2 = om.backbone(sd, cfg, seeded((1, 3, 224, 224), 12))
+        assert np.allclose(o2["res5"][0, ::16].numpy(), g["res5_224_slice"], rtol=1e-4, atol=1e-5)
+        assert np.allclose(om.attnpool(sd, cfg, o2["res5"]).numpy(), g["attnpool_224"], rtol=1e-4, atol=1e-5)
+        assert np.allclose(om.attnpool(sd, cfg, seeded((4, 2048, 7, 7), 13)).numpy(), g["attnpool_rand4"], rtol=1e-4, atol=1e-5)
+        assert np.allclose(om.layer4(sd, cfg, seeded((3, 1024, 14, 14), 14))[:, ::8].numpy(), g["layer4_14"], rtol=1e-4, atol=1e-5)
+
+
+def test_ref_attnpool_grad(sd):
+    g = _npz("ref_attnpool_grad.npz")
+    cfg = om.Cfg()
+    sd = dict(sd)
+    keys = ["backbone.attnpool.q_proj.weight", "backbone.attnpool.c_proj.weight", "backbone.attnpool.positional_embedding"]
+    for k in keys:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    x = seeded((4, 2048, 7, 7), 13).requires_grad_(True)
+    y = om.attnpool(sd, cfg, x)
+    (y * seeded(tuple(y.shape), 15)).sum().backward()
+    assert np.allclose(x.grad[:, ::32].numpy(), g["gx"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(sd[keys[0]].grad[::16, ::16].numpy(), g["gq"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(sd[keys[1]].grad[::16, ::16].numpy(), g["gc"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(sd[keys[2]].grad[:, ::16].numpy(), g["gpos"], rtol=1e-4, atol=1e-6)
+
+
+def test_ref_mapper():
+    g = _npz("ref_mapper.npz")
+    msd = synthetic.make_mapper_state_dict(1)
+    x = seeded((4, 1024), 21).requires_grad_(True)
+    e = om.v2l(msd, om.Cfg(), x)
+    (e * seeded(tuple(e.shape), 22)).sum().backward()
+    assert np.allclose(e.detach().numpy(), g["v2l"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(x.grad.numpy(), g["gx"], rtol=1e-4, atol=1e-6)
+
+
+def test_ref_boxes():
+    g = _npz("ref_boxes.npz")
+    gt, pr = T(g["gt"]), T(g["pr"])
+    iou = oo.pairwise_iou(gt, pr)
+    assert np.array_equal(iou.numpy(), g["iou"])
+    a1, l1 = oo.matcher(iou, [0.3, 0.7], [0, -1, 1], True)
+    a2, l2 = oo.matcher(iou, [0.5], [0, 1], False)
+    assert np.array_equal(a1.numpy(), g["match_rpn"]) and np.array_equal(l1.numpy(), g["label_rpn"])
+    assert np.array_equal(a2.numpy(), g["match_roi"]) and np.array_equal(l2.numpy(), g["label_roi"])
+    pos, neg = oo.subsample_labels(l1, 64, 0.5, 0, torch.Generator().manual_seed(33))
+    assert np.array_equal(pos.numpy(), g["sub_pos"]) and np.array_equal(neg.numpy(), g["sub_neg"])
+    w = (10.0, 10.0, 5.0, 5.0)
+    assert np.allclose(oo.get_deltas(pr[:50], gt[a2[:50]], w).numpy(), g["deltas"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(oo.apply_deltas(T(g["dd"]), pr[:50], w).numpy(), g["applied"], rtol=1e-6, atol=1e-4)
+    assert np.array_equal(oo.grid_anchors(3, 5, 16).numpy(), g["anchors_3x5"])
+
+
+def test_ref_fastrcnn(sd):
+    g = _npz("ref_fastrcnn.npz")
+    cfg = om.Cfg()
+    sd = dict(sd)
+    sd["roi_heads.box_predictor.bbox_pred.bias"] = T(g["bbox_bias"])
+    feats = T(g["feats"]).requires_grad_(True)
+    scores, deltas = om.box_predictor(sd, cfg, feats)
+    assert np.allclose(scores.detach().numpy(), g["scores"], rtol=1e-4, atol=1e-4)
+    assert np.allclose(deltas.detach().numpy(), g["deltas"], rtol=1e-4, atol=1e-5)
+    gcls = T(g["gcls"])
+    lc = om.focal_loss(cfg, scores, gcls)
+    lb = om.box_reg_loss(cfg, T(g["pbox"]), T(g["gbox"]), deltas, gcls)
+    assert np.allclose(float(lc), float(g["loss_cls"]), rtol=1e-5)
+    assert np.allclose(float(lb), float(g["loss_box_reg"]), rtol=1e-5)
+    (lc + lb).backward()
+    assert np.allclose(feats.grad.numpy(), g["gfeats"], rtol=1e-3, atol=1e-6)
+    st = om.classification_stats(scores.detach(), gcls)
+    assert np.allclose([st["fast_rcnn/cls_accuracy"], st["fast_rcnn/fg_cls_accuracy"], st["fast_rcnn/false_negative"]], g["stats"])
+
+
+def test_ref_rpn(sd):
+    g = _npz("ref_rpn.npz")
+    cfg = om.Cfg()
+    feat = T(g["feat"]).requires_grad_(True)
+    props, losses = om.rpn_forward(sd, cfg, feat, [(96, 144), (90, 130)], [T(g["gt0"]), T(g["gt1"])],
+                                   torch.Generator().manual_seed(55), True)
+    assert np.allclose(float(losses["loss_rpn_cls"]), float(g["loss_rpn_cls"]), rtol=1e-5)
+    assert np.allclose(float(losses["loss_rpn_loc"]), float(g["loss_rpn_loc"]), rtol=1e-5)
+    (losses["loss_rpn_cls"] + losses["loss_rpn_loc"]).backward()
+    assert np.allclose(feat.grad.numpy(), g["gfeat"], rtol=1e-3, atol=1e-7)
+    for i in range(2):
+        assert props[i][0].shape == g[f"boxes{i}"].shape  # same NMS keep count (independent python NMS)
+        assert np.allclose(props[i][0].numpy(), g[f"boxes{i}"], rtol=1e-5, atol=1e-4)
+        assert np.allclose(props[i][1].numpy(), g[f"logits{i}"], rtol=1e-5, atol=1e-6)
+
+
+def test_ref_roialign():
+    g = _npz("ref_roialign.npz")
+    x = T(g["x"]).requires_grad_(True)
+    out = oo.roi_align(x, T(g["rois"]), 4, 1.0 / 16, 0, True)
+    assert np.allclose(out.detach().numpy(), g["out"], rtol=1e-5, atol=1e-6)
+    (out * T(g["w"])).sum().backward()
+    assert np.allclose(x.grad.numpy(), g["gx"], rtol=1e-5, atol=1e-6)
