@@ -1,0 +1,468 @@
+// Implicit-GEMM convolution / linear kernels for gfx950 (MI355X, CDNA4), wave64 + MFMA.
+//
+// Replaces on the hot path: ATen conv2d / F.linear as called from the reference's
+//   ModifiedResNet / Bottleneck   detectron2/modeling/backbone/clip_backbone.py:57-70,193-219
+//   FrozenBatchNorm2d             detectron2/layers/batch_norm.py:45-66   (fused epilogue)
+//   StandardRPNHead               detectron2/modeling/proposal_generator/rpn.py:158-177
+//   AttentionPool2d projections   clip_backbone.py:83-107
+//   TransformerMapper linears     detectron2/modeling/backbone/clipcap/clipcap.py:39-163
+//
+// Data layout: activations NHWC (channels contiguous), weights [Cout][KH][KW][Cin] (= torch
+// channels_last OIHW).  Everything is addressed in 16-byte "chunks" along the contraction axis, so
+// one kernel template serves bf16 (8 elem/chunk, v_mfma_f32_32x32x16_bf16) and exact f32
+// (4 elem/chunk, v_mfma_f32_32x32x2_f32, bitwise an fmaf chain) -- the f32 instantiation is the
+// parity path, the bf16 one the throughput path.
+//
+//   conv_fwd  : Y[m,n] = epi( sum_k A[m,k] * W[n,k] ),  A gathered on the fly from NHWC input
+//               (m = (img,oy,ox), k = (ky,kx,c)); epilogue = per-n scale/bias (FrozenBN), residual
+//               add, ReLU, ReLU-backward mask, f32 or T store.  dgrad runs through the same kernel
+//               with flipped/transposed weights (see weight_prep).
+//   conv_wgrad: dW[n,k] += scale[n] * sum_m dY[m,n] * A[m,k]  (reduction over m = pixels), both
+//               operands staged row-major and read transposed (ds_read_b64_tr_b16), split over m
+//               with f32 atomics.
+//
+// Tile: 128x128 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles),
+// K-tile = 8 chunks (128 B per row).  LDS rows are 128 B with chunk ^= (row>>1)&7 so that every
+// ds_read_b128 lane group hits 16 distinct 16-B slots (bank = (addr/4)%64).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, KCH = 8;  // KCH chunks of 16 B per K-tile row
+
+struct ConvArgs {
+  const char* x;
+  const char* w;
+  char* y;
+  const float* scale;
+  const float* bias;
+  const char* residual;
+  const char* relu_mask;
+  int Nimg, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+  int ldy, ldr, ldm;
+  int relu, out_f32, pool;
+  int M, Kc, cpp;  // rows, total K chunks, chunks per pixel
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+  static constexpr int ES = 2;
+  __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ float load(const char* p) { return bf2f(*(const unsigned short*)p); }
+  __device__ static __forceinline__ void store(char* p, float v) { *(unsigned short*)p = f2bf(v); }
+};
+template <> struct Mma<float> {
+  static constexpr int ES = 4;
+  // lane half h holds k = 4h + j in element j; MFMA step j contracts k in {j, 4 + j}: the same
+  // permutation on both operands, so the sum over the chunk pair is exact f32 fma accumulation.
+  __device__ static __forceinline__ void step(f32x16& acc, const u32x4& a, const u32x4& b) {
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0], fb[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1], fb[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[2], fb[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[3], fb[3], acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ float load(const char* p) { return *(const float*)p; }
+  __device__ static __forceinline__ void store(char* p, float v) { *(float*)p = v; }
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * KCH + (chunk ^ ((row >> 1) & 7)); }
+
+// average of 4 packed chunks (2x2 avg-pool fused into the A loader)
+template <typename T> __device__ __forceinline__ u32x4 avg4(const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& d);
+template <> __device__ __forceinline__ u32x4 avg4<float>(const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& d) {
+  const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+  const f32x4 fc = __builtin_bit_cast(f32x4, c), fd = __builtin_bit_cast(f32x4, d);
+  f32x4 r = ((fa + fb) + (fc + fd)) * 0.25f;
+  return __builtin_bit_cast(u32x4, r);
+}
+template <> __device__ __forceinline__ u32x4 avg4<__bf16>(const u32x4& a, const u32x4& b, const u32x4& c, const u32x4& d) {
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float lo = (bf2f(a[j] & 0xffff) + bf2f(b[j] & 0xffff)) + (bf2f(c[j] & 0xffff) + bf2f(d[j] & 0xffff));
+    float hi = (bf2f(a[j] >> 16) + bf2f(b[j] >> 16)) + (bf2f(c[j] >> 16) + bf2f(d[j] >> 16));
+    r[j] = pack2bf(lo * 0.25f, hi * 0.25f);
+  }
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][BM * KCH];
+  const int t = threadIdx.x;
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int cc = t & 7, rb = t >> 3;
+
+  // per-thread A-row geometry (4 rows, fixed across K-tiles)
+  long pix[4];
+  int iy0[4], ix0[4];
+  bool vm[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + rb + 32 * i;
+    vm[i] = m < p.M;
+    int mm = vm[i] ? m : 0;
+    int ox = mm % p.Wo, tq = mm / p.Wo;
+    int oy = tq % p.Ho, img = tq / p.Ho;
+    int s = p.pool ? 2 * p.stride : p.stride;
+    iy0[i] = oy * s - p.pad;
+    ix0[i] = ox * s - p.pad;
+    pix[i] = ((long)img * p.Hi + iy0[i]) * p.Wi + ix0[i];
+  }
+  const int nkt = (p.Kc + KCH - 1) / KCH;
+  u32x4 ra[4], rbv[4];
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+
+  auto gload = [&](int kt) {
+    int kc = kt * KCH + cc;
+    bool vk = kc < p.Kc;
+    int pp = vk ? kc / p.cpp : 0;
+    int coff = vk ? kc - pp * p.cpp : 0;
+    int ky = pp / p.KW, kx = pp - ky * p.KW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      if (!p.pool) {
+        bool ok = vk && vm[i] && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        const u32x4* src = (const u32x4*)(p.x + ((pix[i] + (long)ky * p.Wi + kx) * p.cpp + coff) * 16);
+        ra[i] = ok ? *src : zero;
+      } else {  // 1x1 conv over a 2x2 average-pooled input (floor semantics: Ho = Hi/2)
+        bool ok = vk && vm[i];
+        if (ok) {
+          const char* b0 = p.x + (pix[i] * p.cpp + coff) * 16;
+          long rs = (long)p.Wi * p.cpp * 16, cs = (long)p.cpp * 16;
+          ra[i] = avg4<T>(*(const u32x4*)b0, *(const u32x4*)(b0 + cs), *(const u32x4*)(b0 + rs), *(const u32x4*)(b0 + rs + cs));
+        } else ra[i] = zero;
+      }
+      int n = n0 + rb + 32 * i;
+      bool okb = vk && n < p.Cout;
+      rbv[i] = okb ? *(const u32x4*)(p.w + ((long)n * p.Kc + kc) * 16) : zero;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lane = t & 63, wv = t >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = rb + 32 * i;
+      lds[0][swz(row, cc)] = ra[i];
+      lds[1][swz(row, cc)] = rbv[i];
+    }
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);  // next tile's HBM loads fly under this tile's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < KCH / 2; ++ks) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = lds[0][swz(wm * 64 + i * 32 + r, 2 * ks + h)];
+        fb[i] = lds[1][swz(wn * 64 + i * 32 + r, 2 * ks + h)];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) Mma<T>::step(acc[a][b], fa[a], fb[b]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane&31 (n), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (m)
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    int n = n0 + wn * 64 + b * 32 + r;
+    if (n >= p.Cout) continue;
+    float sc = p.scale ? p.scale[n] : 1.f;
+    float bi = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        int m = m0 + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[a][b][g] * sc + bi;
+        if (p.residual) v += Mma<T>::load(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES);
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu_mask && !(Mma<T>::load(p.relu_mask + ((long)m * p.ldm + n) * Mma<T>::ES) > 0.f)) v = 0.f;
+        if (p.out_f32) *(float*)(p.y + ((long)m * p.ldy + n) * 4) = v;
+        else Mma<T>::store(p.y + ((long)m * p.ldy + n) * Mma<T>::ES, v);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad:  dW[n][k] += scale[n] * sum_m dY[m][n] * A[m][k]
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const char* x;    // NHWC input of the forward conv
+  const char* dy;   // [M][ldd] T
+  float* dw;        // [Cout][K] f32 (K = KH*KW*Cin), accumulated with atomics
+  const float* scale;
+  int Nimg, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ldd, pool;
+  int M, Kc, cpp, K, ncc;  // ncc = chunks per dY row that exist (Cout*ES/16)
+  int mtiles_per_split;
+};
+
+constexpr int WM = 64;                 // m rows per reduction tile
+constexpr int WROW = 16 + 4;           // LDS row = 16 data chunks (256 B) + 4 pad chunks (64 B)
+
+template <typename T> struct TrFrag;
+template <> struct TrFrag<__bf16> {
+  // Reads the MFMA operand fragment (8 reduction elements for column `col`) out of a row-major
+  // [m][col] LDS image with two ds_read_b64_tr_b16: group of 16 lanes <-> 16 columns, lane 4q+p
+  // supplies row q, columns 4p..4p+3, and receives its own column's 4 rows.
+  __device__ static __forceinline__ u32x4 read(const u32x4* base, int mrow0, int col0, int lane) {
+    int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    int hh = g >> 1;                      // lane half = k-group of the MFMA operand
+    int col = col0 + 16 * (g & 1) + 4 * pp;
+    const char* b = (const char*)base;
+    const char* a0 = b + (long)(mrow0 + 8 * hh + q) * (WROW * 16) + col * 2;
+    const char* a1 = a0 + 4 * (WROW * 16);
+    i16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)a0);
+    i16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)a1);
+    u32x2 p0 = __builtin_bit_cast(u32x2, v0), p1 = __builtin_bit_cast(u32x2, v1);
+    u32x4 r = {p0[0], p0[1], p1[0], p1[1]};
+    return r;
+  }
+  static constexpr int MSTEP = 16;  // reduction elements per Mma step
+};
+template <> struct TrFrag<float> {
+  // f32: Mma<float>::step contracts k = 4h + j; element j of lane (r, h) = image[mrow0 + 4h + j][col0 + r]
+  __device__ static __forceinline__ u32x4 read(const u32x4* base, int mrow0, int col0, int lane) {
+    int r = lane & 31, hh = lane >> 5;
+    const char* b = (const char*)base;
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *(const unsigned int*)(b + (long)(mrow0 + 4 * hh + j) * (WROW * 16) + (col0 + r) * 4);
+    return v;
+  }
+  static constexpr int MSTEP = 8;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
+  constexpr int ES = Mma<T>::ES;
+  constexpr int TC = 128 * ES / 16;   // chunks per 128-element tile row (bf16: 16, f32: 32)
+  constexpr int COLS = 256 / ES;      // columns held per LDS image row (bf16: 128, f32: 64)
+  // f32 tiles are 64 columns wide (256 B rows) so both dtypes share the 256 B + pad row geometry.
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][WM * WROW];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int ntn = (p.Cout + COLS - 1) / COLS, ntk = (p.K + COLS - 1) / COLS;
+  int bid = blockIdx.x;
+  const int tile_k = bid % ntk; bid /= ntk;
+  const int tile_n = bid % ntn; bid /= ntn;
+  const int split = bid;
+  const int n0 = tile_n * COLS, k0 = tile_k * COLS;
+  const int mt0 = split * p.mtiles_per_split;
+  const int total_mt = (p.M + WM - 1) / WM;
+  const int mt1 = min(mt0 + p.mtiles_per_split, total_mt);
+  (void)TC;
+
+  // staging map: 64 rows x 16 chunks = 1024 chunks per operand; thread -> chunk cc = t&15, rows t>>4 + 16 i
+  const int cc = t & 15, rb = t >> 4;
+  const int kc = k0 * ES / 16 + cc;          // global K chunk of the A-operand (im2col) column
+  const bool vk = kc < p.Kc;
+  const int pp = vk ? kc / p.cpp : 0, coff = vk ? kc - pp * p.cpp : 0;
+  const int ky = pp / p.KW, kx = pp - ky * p.KW;
+  const int nc = n0 * ES / 16 + cc;          // chunk along dY's channel axis
+  const bool vn = nc < p.ncc;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  u32x4 rx[4], rd[4];
+
+  auto gload = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = mt * WM + rb + 16 * i;
+      bool vmm = m < p.M;
+      int mm = vmm ? m : 0;
+      int ox = mm % p.Wo, tq = mm / p.Wo;
+      int oy = tq % p.Ho, img = tq / p.Ho;
+      if (!p.pool) {
+        int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+        bool ok = vmm && vk && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+        rx[i] = ok ? *(const u32x4*)(p.x + ((((long)img * p.Hi + iy) * p.Wi + ix) * p.cpp + coff) * 16) : zero;
+      } else {
+        if (vmm && vk) {
+          const char* b0 = p.x + ((((long)img * p.Hi + 2 * oy) * p.Wi + 2 * ox) * p.cpp + coff) * 16;
+          long rs = (long)p.Wi * p.cpp * 16, cs = (long)p.cpp * 16;
+          rx[i] = avg4<T>(*(const u32x4*)b0, *(const u32x4*)(b0 + cs), *(const u32x4*)(b0 + rs), *(const u32x4*)(b0 + rs + cs));
+        } else rx[i] = zero;
+      }
+      rd[i] = (vmm && vn) ? *(const u32x4*)(p.dy + ((long)m * p.ldd) * ES + (long)nc * 16) : zero;
+    }
+  };
+
+  // wave tiling of the COLS x COLS output tile: 2x2 waves
+  constexpr int WT = COLS / 2;       // per-wave extent (bf16: 64, f32: 32)
+  constexpr int NT = WT / 32;        // 32x32 tiles per wave per dim (bf16: 2, f32: 1)
+  const int wn = wv >> 1, wk = wv & 1;
+  f32x16 acc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (mt0 < mt1) gload(mt0);
+  for (int mt = mt0; mt < mt1; ++mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = rb + 16 * i;
+      lds[0][row * WROW + cc] = rd[i];
+      lds[1][row * WROW + cc] = rx[i];
+    }
+    __syncthreads();
+    if (mt + 1 < mt1) gload(mt + 1);
+#pragma unroll
+    for (int ms = 0; ms < WM; ms += TrFrag<T>::MSTEP) {
+      u32x4 fa[NT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        fa[i] = TrFrag<T>::read(lds[0], ms, wn * WT + i * 32, lane);
+        fb[i] = TrFrag<T>::read(lds[1], ms, wk * WT + i * 32, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) Mma<T>::step(acc[a][b], fa[a], fb[b]);
+    }
+    __syncthreads();
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      int k = k0 + wk * WT + b * 32 + r;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        int n = n0 + wn * WT + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (n >= p.Cout) continue;
+        float v = acc[a][b][g] * (p.scale ? p.scale[n] : 1.f);
+        atomicAdd(p.dw + (long)n * p.K + k, v);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight_prep: f32 master [Cout][KH][KW][Cin] -> T forward weights (same layout) and T dgrad weights
+// Wd[cin][KH-1-ky][KW-1-kx][cout] = W[cout][ky][kx][cin] * scale[cout]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_weight_prep(const float* w, const float* scale, char* wf, char* wd, int Cout, int KH, int KW, int Cin) {
+  long n = (long)Cout * KH * KW * Cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int ci = i % Cin; long q = i / Cin;
+    int kx = q % KW; q /= KW;
+    int ky = q % KH; int co = q / KH;
+    float v = w[i];
+    if (wf) Mma<T>::store(wf + i * Mma<T>::ES, v);
+    if (wd) {
+      float s = scale ? scale[co] : 1.f;
+      long j = (((long)ci * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * Cout + co;
+      Mma<T>::store(wd + j * Mma<T>::ES, v * s);
+    }
+  }
+}
+
+template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
+  int ntn = (a.Cout + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+  long grid = (long)ntn * ntm;
+  if (grid <= 0) return CDDMSL_OK;
+  if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                               const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin,
+                               int Cout, int KH, int KW, int stride, int pad, int pool, int ldy, int ldr, int ldm,
+                               int relu, int out_f32, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if (dtype != 0 && dtype != 1) return CDDMSL_ERR_ARG;
+  if (Nimg < 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CDDMSL_ERR_ARG;
+  if ((Cin * es) % 16 != 0) return CDDMSL_ERR_ARG;            // channel rows must be whole 16-B chunks
+  if (pool && (KH != 1 || KW != 1 || pad != 0 || stride != 1)) return CDDMSL_ERR_ARG;
+  ConvArgs a;
+  a.x = (const char*)x; a.w = (const char*)w; a.y = (char*)y; a.scale = scale; a.bias = bias;
+  a.residual = (const char*)residual; a.relu_mask = (const char*)relu_mask;
+  a.Nimg = Nimg; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  if (pool) { a.Ho = Hi / 2; a.Wo = Wi / 2; }
+  else { a.Ho = (Hi + 2 * pad - KH) / stride + 1; a.Wo = (Wi + 2 * pad - KW) / stride + 1; }
+  if (a.Ho <= 0 || a.Wo <= 0) return CDDMSL_ERR_ARG;
+  a.ldy = ldy; a.ldr = ldr; a.ldm = ldm; a.relu = relu; a.out_f32 = out_f32; a.pool = pool;
+  long M = (long)Nimg * a.Ho * a.Wo;
+  if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
+  a.M = (int)M; a.cpp = Cin * es / 16; a.Kc = KH * KW * a.cpp;
+  if (a.M == 0) return CDDMSL_OK;
+  return dtype == 0 ? conv_fwd_launch<__bf16>(a, (hipStream_t)stream) : conv_fwd_launch<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const float* scale, int Nimg, int Hi,
+                                 int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int pool, int ldd,
+                                 int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if (dtype != 0 && dtype != 1) return CDDMSL_ERR_ARG;
+  if (Nimg < 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CDDMSL_ERR_ARG;
+  if ((Cin * es) % 16 != 0 || (Cout * es) % 16 != 0 || (ldd * es) % 16 != 0) return CDDMSL_ERR_ARG;
+  if (pool && (KH != 1 || KW != 1 || pad != 0 || stride != 1)) return CDDMSL_ERR_ARG;
+  WgradArgs a;
+  a.x = (const char*)x; a.dy = (const char*)dy; a.dw = dw; a.scale = scale;
+  a.Nimg = Nimg; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.ldd = ldd; a.pool = pool;
+  if (pool) { a.Ho = Hi / 2; a.Wo = Wi / 2; }
+  else { a.Ho = (Hi + 2 * pad - KH) / stride + 1; a.Wo = (Wi + 2 * pad - KW) / stride + 1; }
+  if (a.Ho <= 0 || a.Wo <= 0) return CDDMSL_ERR_ARG;
+  long M = (long)Nimg * a.Ho * a.Wo;
+  if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
+  a.M = (int)M; a.cpp = Cin * es / 16; a.Kc = KH * KW * a.cpp; a.K = KH * KW * Cin; a.ncc = Cout * es / 16;
+  if (a.M == 0) return CDDMSL_OK;
+  int cols = 256 / es;
+  long tiles = (long)((Cout + cols - 1) / cols) * ((a.K + cols - 1) / cols);
+  int total_mt = (a.M + WM - 1) / WM;
+  // enough splits to fill 256 CUs a few times over, but at least 8 m-tiles of work per block
+  long want = (2048 + tiles - 1) / tiles;
+  long maxs = (total_mt + 7) / 8;
+  long splits = want < 1 ? 1 : (want > maxs ? maxs : want);
+  if (splits < 1) splits = 1;
+  a.mtiles_per_split = (int)((total_mt + splits - 1) / splits);
+  splits = (total_mt + a.mtiles_per_split - 1) / a.mtiles_per_split;
+  long grid = tiles * splits;
+  if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_conv_wgrad<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+extern "C" int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int Cout, int KH,
+                                  int KW, int Cin, int dtype, void* stream) {
+  if (dtype != 0 && dtype != 1) return CDDMSL_ERR_ARG;
+  long n = (long)Cout * KH * KW * Cin;
+  if (n <= 0) return n == 0 ? CDDMSL_OK : CDDMSL_ERR_ARG;
+  unsigned grid = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (dtype == 0) hipLaunchKernelGGL(k_weight_prep<__bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, scale, (char*)w_fwd, (char*)w_dgrad, Cout, KH, KW, Cin);
+  else hipLaunchKernelGGL(k_weight_prep<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, scale, (char*)w_fwd, (char*)w_dgrad, Cout, KH, KW, Cin);
+  return launch_status();
+}

@@ -1,0 +1,106 @@
+"""GPU parity: implicit-GEMM conv fwd / dgrad / wgrad (C-ABI) vs ATen CPU fp32 (the oracle's conv)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # N, H, W, Cin, Cout, K, stride, pad
+    (2, 9, 13, 64, 96, 3, 1, 1),
+    (1, 14, 14, 128, 256, 1, 1, 0),
+    (3, 7, 5, 32, 40, 3, 1, 1),
+    (2, 16, 20, 8, 32, 3, 2, 1),
+    (1, 50, 83, 256, 136, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype, tol):
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout, K, s, p = case
+    x = _rand((N, Cin, H, W), 1).to(dtype).float()
+    w = (_rand((Cout, Cin, K, K), 2) * (Cin * K * K) ** -0.5).to(dtype).float()
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(3)) + 0.5
+    bias = _rand((Cout,), 4, 0.1)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    conv = F.conv2d(xr, wr, stride=s, padding=p)
+    res = _rand(tuple(conv.shape), 5).to(dtype).float()
+    y_ref = F.relu(conv * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res)
+    dy = _rand(tuple(conv.shape), 6).to(dtype).float()
+    y_ref.backward(dy)
+
+    dev = "cuda"
+    xg = _nhwc(x).to(dev, dtype)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    wf, wd = hip.weight_prep(w_ohwi, scale.to(dev), dtype)
+    y = hip.conv_fwd(xg, wf, scale.to(dev), bias.to(dev), _nhwc(res).to(dev, dtype), relu=True, stride=s, pad=p)
+    y_cpu = y.float().cpu().permute(0, 3, 1, 2)
+    err = (y_cpu - y_ref.detach()).abs().max() / y_ref.detach().abs().max()
+    assert err < tol, f"fwd err {err}"
+
+    # backward of relu(bn(conv)+res): dpre = dy * (y>0); wgrad uses scale in its epilogue, dgrad in its weights
+    dyg = _nhwc(dy).to(dev, dtype)
+    dpre = (dyg.float() * (y.float() > 0)).to(dtype)
+    dw = hip.conv_wgrad(xg, dpre, (Cout, K, K, Cin), scale.to(dev), stride=s, pad=p)
+    dw_cpu = dw.cpu().permute(0, 3, 1, 2)
+    # reference with the GPU's own relu mask (bf16 rounding can flip y>0 at the boundary)
+    mask = (y_cpu > 0).float()
+    xr2 = x.clone().requires_grad_(True)
+    wr2 = w.clone().requires_grad_(True)
+    c2 = F.conv2d(xr2, wr2, stride=s, padding=p)
+    (c2 * scale.view(1, -1, 1, 1)).backward(dy * mask)
+    errw = (dw_cpu - wr2.grad).abs().max() / wr2.grad.abs().max()
+    assert errw < tol, f"wgrad err {errw}"
+    if s == 1:
+        dx = hip.conv_fwd(dpre, wd, stride=1, pad=K - 1 - p)
+        dx_cpu = dx.float().cpu().permute(0, 3, 1, 2)
+        errx = (dx_cpu - xr2.grad).abs().max() / xr2.grad.abs().max()
+        assert errx < tol, f"dgrad err {errx}"
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_conv_pool_fused(dtype, tol):
+    """AvgPool2d(2) + 1x1 conv (clip_backbone.py:64-65) fused into the A-loader, odd sizes floor."""
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout = 2, 15, 21, 64, 160
+    x = _rand((N, Cin, H, W), 11).to(dtype).float().requires_grad_(True)
+    w = (_rand((Cout, Cin, 1, 1), 12) * Cin ** -0.5).to(dtype).float().requires_grad_(True)
+    y_ref = F.conv2d(F.avg_pool2d(x, 2), w)
+    dy = _rand(tuple(y_ref.shape), 13).to(dtype).float()
+    y_ref.backward(dy)
+    xg = _nhwc(x.detach()).cuda().to(dtype)
+    wf, _ = hip.weight_prep(w.detach().permute(0, 2, 3, 1).contiguous().cuda(), None, dtype)
+    y = hip.conv_fwd(xg, wf, pool=True)
+    assert y.shape == (N, H // 2, W // 2, Cout)
+    err = (y.float().cpu().permute(0, 3, 1, 2) - y_ref.detach()).abs().max() / y_ref.abs().max()
+    assert err < tol
+    dw = hip.conv_wgrad(xg, _nhwc(dy).cuda().to(dtype), (Cout, 1, 1, Cin), None, pool=True)
+    errw = (dw.cpu().permute(0, 3, 1, 2) - w.grad).abs().max() / w.grad.abs().max()
+    assert errw < tol
+
+
+def test_linear_tails():
+    """M, N, K tails (not multiples of the 128x128x64 tile) incl. f32 output from bf16 inputs."""
+    from cddmsl_amd import hip
+    for M, N, K in [(1, 21, 1024), (130, 75, 1032), (257, 129, 8)]:
+        x = _rand((M, K), 21)
+        w = _rand((N, K), 22) * K ** -0.5
+        b = _rand((N,), 23)
+        ref = F.linear(x, w, b)
+        y = hip.linear_fwd(x.cuda(), w.cuda(), None, b.cuda())
+        assert (y.cpu() - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+        yb = hip.linear_fwd(x.cuda().bfloat16(), w.cuda().bfloat16(), None, b.cuda(), out_f32=True)
+        assert yb.dtype == torch.float32
+        assert (yb.cpu() - ref).abs().max() < 3e-2 * max(1.0, float(ref.abs().max()))
