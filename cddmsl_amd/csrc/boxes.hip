@@ -1,0 +1,247 @@
+// Integer/index stages of the RPN and ROI heads on gfx950: anchor decode, sort/top-k, bitmask NMS,
+// fused IoU + matcher.  These are HBM/latency-bound byte and index kernels (no MFMA).
+//
+// Reference call sites replaced (paths under detectron2/):
+//   DefaultAnchorGenerator + Box2BoxTransform.apply_deltas + Boxes.clip/nonempty
+//        modeling/anchor_generator.py:161-228, modeling/box_regression.py:77-115,
+//        modeling/proposal_generator/rpn.py:514-533, structures/boxes.py:193-225
+//   find_top_rpn_proposals (sort desc, top-k, NMS, top-k)   modeling/proposal_generator/proposal_utils.py:22-130
+//   batched_nms -> torchvision.ops.nms                      layers/nms.py:19-39
+//   pairwise_iou + Matcher (+ low-quality matches)          structures/boxes.py:322-367, modeling/matcher.py:61-126
+// Bit-exactness: IoU and NMS use only f32 add/sub/mul/div in the reference's association order with
+// contraction off (no a*b+c patterns exist), IEEE division; indices are therefore identical to the CPU path.
+#include "common.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+// ---------------------------------------------------------------- decode sorted top-k anchors
+// For image n and rank r < topk: a = order[n][r] (index into the H*W*A anchor list, hw-major, a-minor),
+// box = apply_deltas(deltas[n][a], anchor(a)), clipped to (img_h, img_w); valid = finite && nonempty.
+__global__ void k_rpn_decode(const int* order, const float* deltas, const float* cell, const int* img_hw, float* boxes,
+                             unsigned char* valid, int N, int total, int topk, int A, int Wf, float stride, float offset,
+                             float wx, float wy, float ww, float wh, float clampv, float min_size) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * topk) return;
+  int n = i / topk;
+  int a = order[(long)n * total + (i - (long)n * topk)];
+  int ca = a % A, loc = a / A;
+  float sx = offset * stride + (float)(loc % Wf) * stride, sy = offset * stride + (float)(loc / Wf) * stride;
+  float ax0 = sx + cell[4 * ca], ay0 = sy + cell[4 * ca + 1], ax1 = sx + cell[4 * ca + 2], ay1 = sy + cell[4 * ca + 3];
+  const float* d = deltas + ((long)n * total + a) * 4;
+  float w = ax1 - ax0, h = ay1 - ay0;
+  float cx = ax0 + 0.5f * w, cy = ay0 + 0.5f * h;
+  float dx = d[0] / wx, dy = d[1] / wy, dw = fminf(d[2] / ww, clampv), dh = fminf(d[3] / wh, clampv);
+  float pcx = dx * w + cx, pcy = dy * h + cy;
+  float pw = expf(dw) * w, phh = expf(dh) * h;
+  float x0 = pcx - 0.5f * pw, y0 = pcy - 0.5f * phh, x1 = pcx + 0.5f * pw, y1 = pcy + 0.5f * phh;
+  bool fin = isfinite(x0) && isfinite(y0) && isfinite(x1) && isfinite(y1);
+  float ih = (float)img_hw[2 * n], iw = (float)img_hw[2 * n + 1];
+  x0 = fminf(fmaxf(x0, 0.f), iw); x1 = fminf(fmaxf(x1, 0.f), iw);
+  y0 = fminf(fmaxf(y0, 0.f), ih); y1 = fminf(fmaxf(y1, 0.f), ih);
+  float* o = boxes + i * 4;
+  o[0] = x0; o[1] = y0; o[2] = x1; o[3] = y1;
+  valid[i] = fin ? (((x1 - x0) > min_size && (y1 - y0) > min_size) ? 1 : 0) : 2;  // 2 = non-finite
+}
+
+// all anchors decoded (no ordering): used for parity checks and by the matcher path
+__global__ void k_anchors(const float* cell, float* out, int total, int A, int Wf, float stride, float offset) {
+  int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= total) return;
+  int ca = a % A, loc = a / A;
+  float sx = offset * stride + (float)(loc % Wf) * stride, sy = offset * stride + (float)(loc / Wf) * stride;
+  out[4 * a] = sx + cell[4 * ca]; out[4 * a + 1] = sy + cell[4 * ca + 1];
+  out[4 * a + 2] = sx + cell[4 * ca + 2]; out[4 * a + 3] = sy + cell[4 * ca + 3];
+}
+
+__global__ void k_iota_segments(int* idx, int N, int total) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (long)N * total) idx[i] = (int)(i % total);
+}
+
+// ---------------------------------------------------------------- bitmask NMS
+// boxes [N][n][4] in descending-score order; valid [N][n].  mask[N][n][nw] (nw = ceil(n/64)) bit j of word w of
+// row i set when j = 64w+bit > i and IoU(i,j) > thr.  64-wide wavefront <-> 64-bit mask word.
+__global__ void k_nms_mask(const float* boxes, unsigned long long* mask, int n, int nw, float thr) {
+  int img = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;  // only j > i matters
+  const float* b = boxes + (long)img * n * 4;
+  __shared__ float cbx[64 * 4];
+  int t = threadIdx.x;
+  int cj = cb * 64 + t;
+  if (cj < n) { cbx[4 * t] = b[4 * cj]; cbx[4 * t + 1] = b[4 * cj + 1]; cbx[4 * t + 2] = b[4 * cj + 2]; cbx[4 * t + 3] = b[4 * cj + 3]; }
+  __syncthreads();
+  int i = rb * 64 + t;
+  if (i >= n) return;
+  float x0 = b[4 * i], y0 = b[4 * i + 1], x1 = b[4 * i + 2], y1 = b[4 * i + 3];
+  float ai = (x1 - x0) * (y1 - y0);
+  unsigned long long bits = 0;
+  int jn = min(64, n - cb * 64);
+  for (int j = (rb == cb ? t + 1 : 0); j < jn; ++j) {
+    float xx1 = fmaxf(x0, cbx[4 * j]), yy1 = fmaxf(y0, cbx[4 * j + 1]);
+    float xx2 = fminf(x1, cbx[4 * j + 2]), yy2 = fminf(y1, cbx[4 * j + 3]);
+    float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+    float inter = w * h;
+    float aj = (cbx[4 * j + 2] - cbx[4 * j]) * (cbx[4 * j + 3] - cbx[4 * j + 1]);
+    float iou = inter / (ai + aj - inter);
+    if (iou > thr) bits |= 1ull << j;
+  }
+  mask[((long)img * n + i) * nw + cb] = bits;
+}
+// one wave per image: lanes hold the `removed` words; scan rows in order.
+__global__ void k_nms_scan(const unsigned long long* mask, const unsigned char* valid, int* keep, int* nkeep, int n, int nw,
+                           int max_keep) {
+  int img = blockIdx.x, lane = threadIdx.x;
+  const unsigned long long* m = mask + (long)img * n * nw;
+  const unsigned char* v = valid + (long)img * n;
+  constexpr int WPL = 8;  // words per lane -> up to 64*8*64 = 32768 boxes
+  unsigned long long removed[WPL];
+#pragma unroll
+  for (int q = 0; q < WPL; ++q) removed[q] = 0;
+  int cnt = 0;
+  for (int i = 0; i < n && cnt < max_keep; ++i) {
+    int w = i >> 6;
+    unsigned long long word = 0;
+#pragma unroll
+    for (int q = 0; q < WPL; ++q) if ((w >> 6) == q) word = removed[q];
+    word = __shfl(word, w & 63, 64);
+    bool dead = ((word >> (i & 63)) & 1ull) || v[i] != 1;
+    if (dead) continue;      // uniform
+    if (lane == 0) keep[(long)img * max_keep + cnt] = i;
+    ++cnt;
+#pragma unroll
+    for (int q = 0; q < WPL; ++q) {
+      int ww = q * 64 + lane;
+      if (ww < nw && ww >= w) removed[q] |= m[(long)i * nw + ww];
+    }
+  }
+  if (lane == 0) nkeep[img] = cnt;
+}
+
+// ---------------------------------------------------------------- fused IoU + Matcher
+__device__ __forceinline__ float iou_pair(const float* g, float x0, float y0, float x1, float y1, float ap) {
+  float w = fminf(g[2], x1) - fmaxf(g[0], x0);
+  float h = fminf(g[3], y1) - fmaxf(g[1], y0);
+  w = fmaxf(w, 0.f); h = fmaxf(h, 0.f);
+  float inter = w * h;
+  float ag = (g[2] - g[0]) * (g[3] - g[1]);
+  return inter > 0.f ? inter / (ag + ap - inter) : 0.f;
+}
+// pass 1: per prediction j: max/argmax over gt (first max), threshold label; per gt: atomic max over j.
+// gt [G][4] for this image, preds [P][4].  thresholds: up to 2 cut points t0 <= t1 with labels l0,l1,l2.
+__global__ void k_match1(const float* gt, int G, const float* preds, int P, long* matches, signed char* labels,
+                         unsigned int* best_gt, int nthr, float t0, float t1, int l0, int l1, int l2) {
+  extern __shared__ float sg[];
+  for (int i = threadIdx.x; i < G * 4; i += blockDim.x) sg[i] = gt[i];
+  __syncthreads();
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = j < P;
+  int jj = live ? j : 0;
+  float x0 = preds[4 * jj], y0 = preds[4 * jj + 1], x1 = preds[4 * jj + 2], y1 = preds[4 * jj + 3];
+  float ap = (x1 - x0) * (y1 - y0);
+  float best = -1.f; int arg = 0;
+  for (int g = 0; g < G; ++g) {
+    float v = iou_pair(sg + 4 * g, x0, y0, x1, y1, ap);
+    if (v > best) { best = v; arg = g; }
+    if (best_gt) {   // per-gt max over predictions: wave max first, one atomic per wave (v >= 0: uint order == float order)
+      float wm = wave_max(live ? v : 0.f);
+      if ((threadIdx.x & 63) == 0) atomicMax(best_gt + g, __float_as_uint(wm));
+    }
+  }
+  if (!live) return;
+  int lab;
+  if (nthr == 1) lab = best < t0 ? l0 : l1;
+  else lab = best < t0 ? l0 : (best < t1 ? l1 : l2);
+  matches[j] = arg;
+  labels[j] = (signed char)lab;
+}
+// pass 2 (allow_low_quality_matches): label 1 for every prediction attaining some gt's row max (ties included)
+__global__ void k_match2(const float* gt, int G, const float* preds, int P, signed char* labels, const unsigned int* best_gt) {
+  extern __shared__ float sg[];
+  for (int i = threadIdx.x; i < G * 4; i += blockDim.x) sg[i] = gt[i];
+  __syncthreads();
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  float x0 = preds[4 * j], y0 = preds[4 * j + 1], x1 = preds[4 * j + 2], y1 = preds[4 * j + 3];
+  float ap = (x1 - x0) * (y1 - y0);
+  bool hit = false;
+  for (int g = 0; g < G; ++g) {
+    float v = iou_pair(sg + 4 * g, x0, y0, x1, y1, ap);
+    hit |= (__float_as_uint(v) == best_gt[g]);
+  }
+  if (hit) labels[j] = 1;
+}
+
+}  // namespace
+
+extern "C" int cddmsl_anchors(const float* cell, float* out, int Hf, int Wf, int A, float stride, float offset, void* stream) {
+  int total = Hf * Wf * A;
+  if (total <= 0) return total == 0 ? CDDMSL_OK : CDDMSL_ERR_ARG;
+  k_anchors<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(cell, out, total, A, Wf, stride, offset);
+  return launch_status();
+}
+
+// Segmented stable descending sort of logits [N][total] -> sorted keys + order (int32 index within the image).
+// Call with temp == NULL to get the workspace size in *temp_bytes.
+extern "C" int cddmsl_sort_desc(const float* keys_in, float* keys_out, int* idx_scratch, int* order_out, const int* offsets,
+                                int N, int total, void* temp, size_t* temp_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 0 || total <= 0) return CDDMSL_ERR_ARG;
+  size_t bytes = temp ? *temp_bytes : 0;
+  if (temp) {
+    long n = (long)N * total;
+    k_iota_segments<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(idx_scratch, N, total);
+  }
+  hipError_t e = rocprim::segmented_radix_sort_pairs_desc(temp, bytes, keys_in, keys_out, idx_scratch, order_out,
+                                                         (unsigned)((long)N * total), (unsigned)N, offsets, offsets + 1,
+                                                         0, 32, st);
+  if (!temp) *temp_bytes = bytes;
+  if (e != hipSuccess) return CDDMSL_ERR_LAUNCH;
+  return launch_status();
+}
+
+extern "C" int cddmsl_rpn_decode(const int* order, const float* deltas, const float* cell, const int* img_hw, float* boxes,
+                                 unsigned char* valid, int N, int Hf, int Wf, int A, int topk, float stride, float offset,
+                                 float wx, float wy, float ww, float wh, float scale_clamp, float min_size, void* stream) {
+  int total = Hf * Wf * A;
+  if (N <= 0 || total <= 0 || topk <= 0 || topk > total) return CDDMSL_ERR_ARG;
+  long n = (long)N * topk;
+  k_rpn_decode<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      order, deltas, cell, img_hw, boxes, valid, N, total, topk, A, Wf, stride, offset, wx, wy, ww, wh, scale_clamp, min_size);
+  return launch_status();
+}
+
+// boxes [N][n][4] score-descending, valid [N][n] (1 = candidate).  mask_ws: N*n*ceil(n/64) u64.
+// keep [N][max_keep] (positions into the sorted list, score order), nkeep [N].
+extern "C" int cddmsl_nms(const float* boxes, const unsigned char* valid, unsigned long long* mask_ws, int* keep, int* nkeep,
+                          int N, int n, float thr, int max_keep, void* stream) {
+  if (N <= 0 || n < 0 || max_keep <= 0 || n > 32768) return CDDMSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return hipMemsetAsync(nkeep, 0, sizeof(int) * N, st) == hipSuccess ? CDDMSL_OK : CDDMSL_ERR_LAUNCH;
+  int nw = (n + 63) / 64;
+  k_nms_mask<<<dim3(nw, nw, N), dim3(64), 0, st>>>(boxes, mask_ws, n, nw, thr);
+  k_nms_scan<<<dim3(N), dim3(64), 0, st>>>(mask_ws, valid, keep, nkeep, n, nw, max_keep);
+  return launch_status();
+}
+
+// One image: gt [G][4], preds [P][4] -> matches int64 [P], labels int8 [P].  best_ws: G uints (zeroed here).
+extern "C" int cddmsl_iou_match(const float* gt, int G, const float* preds, int P, long* matches, signed char* labels,
+                                unsigned int* best_ws, int nthr, float t0, float t1, int l0, int l1, int l2,
+                                int allow_low_quality, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (G < 0 || P < 0 || nthr < 1 || nthr > 2 || G > 4096) return CDDMSL_ERR_ARG;
+  if (P == 0) return CDDMSL_OK;
+  if (G == 0) {  // matcher.py:75-86: all predictions get labels[0], match 0
+    if (hipMemsetAsync(matches, 0, sizeof(long) * P, st) != hipSuccess) return CDDMSL_ERR_LAUNCH;
+    if (hipMemsetAsync(labels, l0 & 0xff, P, st) != hipSuccess) return CDDMSL_ERR_LAUNCH;
+    return CDDMSL_OK;
+  }
+  unsigned int* bw = allow_low_quality ? best_ws : nullptr;
+  if (bw && hipMemsetAsync(bw, 0, sizeof(unsigned int) * G, st) != hipSuccess) return CDDMSL_ERR_LAUNCH;
+  dim3 grid((P + 255) / 256), block(256);
+  size_t sh = sizeof(float) * 4 * G;
+  k_match1<<<grid, block, sh, st>>>(gt, G, preds, P, matches, labels, bw, nthr, t0, t1, l0, l1, l2);
+  if (allow_low_quality) k_match2<<<grid, block, sh, st>>>(gt, G, preds, P, labels, bw);
+  return launch_status();
+}

@@ -1,0 +1,346 @@
+// HBM-bound elementwise / pooling kernels of the CDDMSL hot path (gfx950, wave64).
+//
+//   preprocess      GeneralizedRCNN.preprocess_image  detectron2/modeling/meta_arch/rcnn.py:758-768
+//                   + ImageList.from_tensors zero pad  detectron2/structures/image_list.py:72-124
+//                   u8 CHW image -> (x/255 - mean)/std -> NHWC T, channel-padded, zero outside the image
+//   preprocess224   preprocess_image_train            rcnn.py:161-179 (x/255 -> pad -> bicubic short side
+//                   224, align_corners=False, no antialias -> center crop 224 -> normalise)
+//   avgpool2        nn.AvgPool2d(2) (floor)           clip_backbone.py:36,46,147 forward/backward
+//   attn tokens     AttentionPool2d token build        clip_backbone.py:84-86 forward/backward
+//   sgd_clip        per-parameter grad-norm clip + SGD detectron2/solver/build.py:59-67,104,113-130
+// All kernels read/write 16 B per lane where the layout allows (channels contiguous).
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Elt;
+template <> struct Elt<__bf16> {
+  static constexpr int ES = 2, VEC = 8;
+  __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f(v[j] & 0xffff); f[2 * j + 1] = bf2f(v[j] >> 16); }
+  }
+  __device__ static __forceinline__ u32x4 pack(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+    return v;
+  }
+  __device__ static __forceinline__ float ld(const char* p) { return bf2f(*(const unsigned short*)p); }
+  __device__ static __forceinline__ void st(char* p, float v) { *(unsigned short*)p = f2bf(v); }
+};
+template <> struct Elt<float> {
+  static constexpr int ES = 4, VEC = 4;
+  __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+    const f32x4 x = __builtin_bit_cast(f32x4, v);
+    f[0] = x[0]; f[1] = x[1]; f[2] = x[2]; f[3] = x[3];
+  }
+  __device__ static __forceinline__ u32x4 pack(const float* f) {
+    f32x4 x = {f[0], f[1], f[2], f[3]};
+    return __builtin_bit_cast(u32x4, x);
+  }
+  __device__ static __forceinline__ float ld(const char* p) { return *(const float*)p; }
+  __device__ static __forceinline__ void st(char* p, float v) { *(float*)p = v; }
+};
+
+// ---------------------------------------------------------------- preprocess (full resolution)
+template <typename T>
+__global__ void k_preprocess(const unsigned char* img, char* out, int n, int h, int w, int Hp, int Wp, int Cp,
+                             float m0, float m1, float m2, float s0, float s1, float s2) {
+  // one thread per padded output pixel of image n; out[n][y][x][0..Cp)
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Hp * Wp) return;
+  int x = i % Wp, y = i / Wp;
+  float v[3] = {0.f, 0.f, 0.f};
+  if (y < h && x < w) {
+    long o = (long)y * w + x, pl = (long)h * w;
+    v[0] = ((float)img[o] / 255.0f - m0) / s0;
+    v[1] = ((float)img[pl + o] / 255.0f - m1) / s1;
+    v[2] = ((float)img[2 * pl + o] / 255.0f - m2) / s2;
+  }
+  char* dst = out + (((long)n * Hp + y) * Wp + x) * Cp * Elt<T>::ES;
+  for (int c = 0; c < Cp; ++c) Elt<T>::st(dst + c * Elt<T>::ES, c < 3 ? v[c] : 0.f);
+}
+
+// ---------------------------------------------------------------- 224 bicubic preprocess
+// ATen upsample_bicubic2d (align_corners=False): src = (dst+0.5)*scale-0.5, A=-0.75, taps clamped.
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+template <typename T>
+__global__ void k_preprocess224(const unsigned char* img, char* out, int n, int h, int w, int Hp, int Wp,
+                                int RH, int RW, int top, int left, int S, int Cp,
+                                float m0, float m1, float m2, float s0, float s1, float s2) {
+  // (h,w): this image; (Hp,Wp): padded batch size (zero outside the image); (RH,RW): resized padded size;
+  // crop window (top,left,S,S).  One thread per output pixel.
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * S) return;
+  int ox = i % S, oy = i / S;
+  float sy = (float)Hp / (float)RH, sx = (float)Wp / (float)RW;
+  float fy = ((float)(oy + top) + 0.5f) * sy - 0.5f, fx = ((float)(ox + left) + 0.5f) * sx - 0.5f;
+  int iy = (int)floorf(fy), ix = (int)floorf(fx);
+  float ty = fy - iy, tx = fx - ix;
+  const float A = -0.75f;
+  float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+  float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+  float acc[3] = {0.f, 0.f, 0.f};
+  long pl = (long)h * w;
+  for (int a = 0; a < 4; ++a) {
+    int yy = min(max(iy - 1 + a, 0), Hp - 1);
+    float r[3] = {0.f, 0.f, 0.f};
+    for (int b = 0; b < 4; ++b) {
+      int xx = min(max(ix - 1 + b, 0), Wp - 1);
+      if (yy < h && xx < w) {
+        long o = (long)yy * w + xx;
+        r[0] += wx[b] * ((float)img[o] / 255.0f);
+        r[1] += wx[b] * ((float)img[pl + o] / 255.0f);
+        r[2] += wx[b] * ((float)img[2 * pl + o] / 255.0f);
+      }
+    }
+    acc[0] += wy[a] * r[0]; acc[1] += wy[a] * r[1]; acc[2] += wy[a] * r[2];
+  }
+  float v[3] = {(acc[0] - m0) / s0, (acc[1] - m1) / s1, (acc[2] - m2) / s2};
+  char* dst = out + (((long)n * S + oy) * S + ox) * Cp * Elt<T>::ES;
+  for (int c = 0; c < Cp; ++c) Elt<T>::st(dst + c * Elt<T>::ES, c < 3 ? v[c] : 0.f);
+}
+
+// ---------------------------------------------------------------- avgpool 2x2 (NHWC)
+template <typename T>
+__global__ void k_avgpool2_fwd(const char* x, char* y, int N, int H, int W, int cch) {
+  // cch = 16-B chunks per pixel; one thread per output chunk
+  int Ho = H / 2, Wo = W / 2;
+  long total = (long)N * Ho * Wo * cch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cch; long q = i / cch;
+    int ox = q % Wo; q /= Wo;
+    int oy = q % Ho; int n = q / Ho;
+    const u32x4* b = (const u32x4*)x + (((long)n * H + 2 * oy) * W + 2 * ox) * cch + c;
+    float a0[8], a1[8], a2[8], a3[8], o[8];
+    Elt<T>::unpack(b[0], a0); Elt<T>::unpack(b[cch], a1);
+    Elt<T>::unpack(b[(long)W * cch], a2); Elt<T>::unpack(b[(long)W * cch + cch], a3);
+#pragma unroll
+    for (int j = 0; j < Elt<T>::VEC; ++j) o[j] = ((a0[j] + a1[j]) + (a2[j] + a3[j])) * 0.25f;
+    ((u32x4*)y)[i] = Elt<T>::pack(o);
+  }
+}
+
+// dx[n][y][x] = (dy[n][y/2][x/2] / 4) (+ add[n][y][x]) masked by (mask > 0); zero on the floor-dropped row/col
+template <typename T>
+__global__ void k_avgpool2_bwd(const char* dy, const char* mask, const char* add, char* dx, int N, int H, int W, int cch) {
+  int Ho = H / 2, Wo = W / 2;
+  long total = (long)N * H * W * cch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cch; long q = i / cch;
+    int xx = q % W; q /= W;
+    int yy = q % H; int n = q / H;
+    float g[8], m[8], a[8], o[8];
+    bool in = (yy >> 1) < Ho && (xx >> 1) < Wo;
+    if (in) Elt<T>::unpack(((const u32x4*)dy)[(((long)n * Ho + (yy >> 1)) * Wo + (xx >> 1)) * cch + c], g);
+    if (mask) Elt<T>::unpack(((const u32x4*)mask)[i], m);
+    if (add) Elt<T>::unpack(((const u32x4*)add)[i], a);
+#pragma unroll
+    for (int j = 0; j < Elt<T>::VEC; ++j) {
+      float v = in ? g[j] * 0.25f : 0.f;
+      if (add) v += a[j];
+      if (mask && !(m[j] > 0.f)) v = 0.f;
+      o[j] = v;
+    }
+    ((u32x4*)dx)[i] = Elt<T>::pack(o);
+  }
+}
+
+// ---------------------------------------------------------------- attention-pool tokens
+// x [K][P][C] (P = 49 pixels) -> tok [K][P+1][C]: tok0 = mean_p x + pos[0], tok_{i+1} = x_i + pos[i+1]
+template <typename T>
+__global__ void k_attn_tokens_fwd(const char* x, const float* pos, char* tok, int K, int P, int cch) {
+  long total = (long)K * cch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cch; long k = i / cch;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8], o[8];
+    const int VEC = Elt<T>::VEC;
+    for (int p = 0; p < P; ++p) {
+      Elt<T>::unpack(((const u32x4*)x)[(k * P + p) * cch + c], v);
+      const float* pe = pos + (long)(p + 1) * cch * VEC + c * VEC;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s[j] += v[j]; o[j] = v[j] + pe[j]; }
+      ((u32x4*)tok)[(k * (P + 1) + p + 1) * cch + c] = Elt<T>::pack(o);
+    }
+    const float* pe = pos + c * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = s[j] / (float)P + pe[j];
+    ((u32x4*)tok)[(k * (P + 1)) * cch + c] = Elt<T>::pack(o);
+  }
+}
+// dx[k][p] = dtok[k][p+1] + dtok[k][0]/P
+template <typename T>
+__global__ void k_attn_tokens_bwd(const char* dtok, char* dx, int K, int P, int cch) {
+  long total = (long)K * P * cch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cch; long q = i / cch;
+    int p = q % P; long k = q / P;
+    float a[8], b[8], o[8];
+    Elt<T>::unpack(((const u32x4*)dtok)[(k * (P + 1) + p + 1) * cch + c], a);
+    Elt<T>::unpack(((const u32x4*)dtok)[(k * (P + 1)) * cch + c], b);
+#pragma unroll
+    for (int j = 0; j < Elt<T>::VEC; ++j) o[j] = a[j] + b[j] / (float)P;
+    ((u32x4*)dx)[i] = Elt<T>::pack(o);
+  }
+}
+
+// column sums: out[c] (f32) += sum_r x[r][c]  (bias grads, positional-embedding grads with row period)
+template <typename T>
+__global__ void k_colsum(const char* x, float* out, long rows, int cols, int period) {
+  // grid.x over column blocks of 64, grid.y over row slabs; out index = (r % period) * cols + c
+  int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  int rlane = threadIdx.x >> 6;           // 4 row lanes
+  long r0 = (long)blockIdx.y * 256;
+  if (c >= cols) return;
+  if (period == 1) {
+    float s = 0.f;
+    for (long r = r0 + rlane; r < min(rows, r0 + 256); r += 4) s += Elt<T>::ld(x + (r * cols + c) * Elt<T>::ES);
+    atomicAdd(out + c, s);
+  } else {
+    for (long r = r0 + rlane; r < min(rows, r0 + 256); r += 4)
+      atomicAdd(out + (r % period) * cols + c, Elt<T>::ld(x + (r * cols + c) * Elt<T>::ES));
+  }
+}
+
+// ---------------------------------------------------------------- fused clip + SGD (multi-tensor, 2 passes)
+struct SgdItem { float* p; const float* g; float* m; long n; };
+constexpr int SGD_MAX = 96;
+struct SgdBatch { SgdItem it[SGD_MAX]; int count; };
+
+__global__ void k_sqnorm(SgdBatch b, float* norms) {
+  // grid.y = tensor, grid.x = slab
+  const SgdItem& t = b.it[blockIdx.y];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += (long)gridDim.x * blockDim.x) {
+    float g = t.g[i];
+    s += g * g;
+  }
+  s = wave_sum(s);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(norms + blockIdx.y, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void k_sgd(SgdBatch b, const float* norms, float lr, float momentum, float wd, float clip, int first_step) {
+  const SgdItem& t = b.it[blockIdx.y];
+  float nrm = sqrtf(norms[blockIdx.y]);
+  float coef = fminf(clip / (nrm + 1e-6f), 1.0f);   // torch.nn.utils.clip_grad_norm_
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += (long)gridDim.x * blockDim.x) {
+    float p = t.p[i];
+    float g = t.g[i] * coef + wd * p;
+    float m = first_step ? g : momentum * t.m[i] + g;
+    t.m[i] = m;
+    t.p[i] = p - lr * m;
+  }
+}
+
+inline unsigned gsz(long n, int per = 256, long cap = 8192) {
+  long g = (n + per - 1) / per;
+  return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, KERNEL, ...)                                   \
+  do {                                                                 \
+    if ((dtype) == 0) { KERNEL<__bf16> __VA_ARGS__; }                  \
+    else if ((dtype) == 1) { KERNEL<float> __VA_ARGS__; }              \
+    else return CDDMSL_ERR_ARG;                                        \
+  } while (0)
+
+extern "C" int cddmsl_preprocess(const unsigned char* img, void* out, int n, int h, int w, int Hp, int Wp, int Cp,
+                                 const float* mean3, const float* std3, int dtype, void* stream) {
+  if (h <= 0 || w <= 0 || h > Hp || w > Wp || Cp < 3) return CDDMSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  long px = (long)Hp * Wp;
+  DISPATCH(dtype, k_preprocess, <<<dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st>>>(
+      img, (char*)out, n, h, w, Hp, Wp, Cp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]));
+  return launch_status();
+}
+
+extern "C" int cddmsl_preprocess224(const unsigned char* img, void* out, int n, int h, int w, int Hp, int Wp, int RH,
+                                    int RW, int top, int left, int S, int Cp, const float* mean3, const float* std3,
+                                    int dtype, void* stream) {
+  if (h <= 0 || w <= 0 || h > Hp || w > Wp || Cp < 3 || S <= 0 || top < 0 || left < 0 || top + S > RH || left + S > RW)
+    return CDDMSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype, k_preprocess224, <<<dim3((unsigned)((S * S + 255) / 256)), dim3(256), 0, st>>>(
+      img, (char*)out, n, h, w, Hp, Wp, RH, RW, top, left, S, Cp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]));
+  return launch_status();
+}
+
+extern "C" int cddmsl_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((C * es) % 16 || H < 2 || W < 2) return CDDMSL_ERR_ARG;
+  int cch = C * es / 16;
+  long total = (long)N * (H / 2) * (W / 2) * cch;
+  if (total == 0) return CDDMSL_OK;
+  DISPATCH(dtype, k_avgpool2_fwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)x, (char*)y, N, H, W, cch));
+  return launch_status();
+}
+
+extern "C" int cddmsl_avgpool2_bwd(const void* dy, const void* mask, const void* add, void* dx, int N, int H, int W,
+                                   int C, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((C * es) % 16 || H < 2 || W < 2) return CDDMSL_ERR_ARG;
+  int cch = C * es / 16;
+  long total = (long)N * H * W * cch;
+  if (total == 0) return CDDMSL_OK;
+  DISPATCH(dtype, k_avgpool2_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>(
+      (const char*)dy, (const char*)mask, (const char*)add, (char*)dx, N, H, W, cch));
+  return launch_status();
+}
+
+extern "C" int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int C, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((C * es) % 16 || P <= 0) return CDDMSL_ERR_ARG;
+  int cch = C * es / 16;
+  long total = (long)K * cch;
+  if (total == 0) return CDDMSL_OK;
+  DISPATCH(dtype, k_attn_tokens_fwd, <<<dim3(gsz(total, 64)), dim3(64), 0, (hipStream_t)stream>>>((const char*)x, pos, (char*)tok, K, P, cch));
+  return launch_status();
+}
+
+extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, int C, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((C * es) % 16 || P <= 0) return CDDMSL_ERR_ARG;
+  int cch = C * es / 16;
+  long total = (long)K * P * cch;
+  if (total == 0) return CDDMSL_OK;
+  DISPATCH(dtype, k_attn_tokens_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (char*)dx, K, P, cch));
+  return launch_status();
+}
+
+// out (f32, caller-zeroed or accumulated into) [period][cols] += column sums of x [rows][cols]
+extern "C" int cddmsl_colsum(const void* x, float* out, long rows, int cols, int period, int dtype, void* stream) {
+  if (rows < 0 || cols <= 0 || period <= 0) return CDDMSL_ERR_ARG;
+  if (rows == 0) return CDDMSL_OK;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 255) / 256));
+  DISPATCH(dtype, k_colsum, <<<grid, dim3(256), 0, (hipStream_t)stream>>>((const char*)x, out, rows, cols, period));
+  return launch_status();
+}
+
+// Multi-tensor step: ptr arrays live on the host; tensors are batched SGD_MAX per launch pair.
+extern "C" int cddmsl_sgd_clip_step(float** params, const float** grads, float** moms, const long* sizes, int count,
+                                    float* norm_ws, float lr, float momentum, float wd, float clip, int first_step,
+                                    void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (count < 0) return CDDMSL_ERR_ARG;
+  for (int base = 0; base < count; base += SGD_MAX) {
+    SgdBatch b;
+    b.count = count - base < SGD_MAX ? count - base : SGD_MAX;
+    long mx = 0;
+    for (int i = 0; i < b.count; ++i) {
+      b.it[i].p = params[base + i]; b.it[i].g = grads[base + i]; b.it[i].m = moms[base + i]; b.it[i].n = sizes[base + i];
+      if (sizes[base + i] > mx) mx = sizes[base + i];
+    }
+    if (hipMemsetAsync(norm_ws + base, 0, sizeof(float) * b.count, st) != hipSuccess) return CDDMSL_ERR_LAUNCH;
+    unsigned gx = gsz(mx, 256 * 8, 256);
+    k_sqnorm<<<dim3(gx, b.count), dim3(256), 0, st>>>(b, norm_ws + base);
+    k_sgd<<<dim3(gx, b.count), dim3(256), 0, st>>>(b, norm_ws + base, lr, momentum, wd, clip, first_step);
+  }
+  return launch_status();
+}

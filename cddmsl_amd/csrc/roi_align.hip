@@ -1,0 +1,247 @@
+// RoIAlign forward / backward for gfx950, channels-last.
+//
+// Replaces torchvision.ops.roi_align as called from the reference:
+//   ROIAlign.forward   detectron2/layers/roi_align.py:49-65  (aligned=True, sampling_ratio=0, scale 1/16)
+//   ROIPooler.forward  detectron2/modeling/poolers.py:190-229
+// Algorithm = torchvision's: adaptive sample grid ceil(roi/pooled), bilinear
+// with the [-1, H] validity window, clamp at 0, top edge snap to H-1.
+//
+// Layout: feature map NHWC [N][H][W][C], rois [K][5] f32 (batch, x0, y0, x1, y1), output [K][ph][pw][C]
+// (= K images of ph x pw for the RoI layer4 convs).  16 B per lane along C everywhere.
+//
+// Backward avoids global atomics (the reference's CUDA path scatter-adds): bilinear weights are
+// separable, so sum_samples w(y,x) = Ay[py][bi] * Ax[px][bj] with per-RoI, per-axis tables
+// (k_roi_tables).  The gather kernel then walks, for every feature pixel, the RoIs of its image whose
+// footprint covers it and accumulates Ay*Ax*dY in registers -- deterministic, written once.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Vec;
+template <> struct Vec<__bf16> {
+  static constexpr int ES = 2, VEC = 8;
+  __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f(v[j] & 0xffff); f[2 * j + 1] = bf2f(v[j] >> 16); }
+  }
+  __device__ static __forceinline__ u32x4 pack(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+    return v;
+  }
+};
+template <> struct Vec<float> {
+  static constexpr int ES = 4, VEC = 4;
+  __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+    const f32x4 x = __builtin_bit_cast(f32x4, v);
+    f[0] = x[0]; f[1] = x[1]; f[2] = x[2]; f[3] = x[3];
+  }
+  __device__ static __forceinline__ u32x4 pack(const float* f) {
+    f32x4 x = {f[0], f[1], f[2], f[3]};
+    return __builtin_bit_cast(u32x4, x);
+  }
+};
+
+struct RoiGeom {
+  int b, gh, gw;
+  float x0, y0, bh, bw;
+};
+__device__ __forceinline__ RoiGeom roi_geom(const float* r, float scale, int ph, int pw, int sampling_ratio, int aligned) {
+  RoiGeom g;
+  g.b = (int)r[0];
+  float off = aligned ? 0.5f : 0.0f;
+  g.x0 = r[1] * scale - off; g.y0 = r[2] * scale - off;
+  float x1 = r[3] * scale - off, y1 = r[4] * scale - off;
+  float rw = x1 - g.x0, rh = y1 - g.y0;
+  if (!aligned) { rw = fmaxf(rw, 1.0f); rh = fmaxf(rh, 1.0f); }
+  g.bh = rh / (float)ph; g.bw = rw / (float)pw;
+  g.gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)ph);
+  g.gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)pw);
+  return g;
+}
+// one axis of the bilinear tap: returns false when the sample is outside [-1, L]
+__device__ __forceinline__ bool axis_tap(float v, int L, int& lo, int& hi, float& wl, float& wh) {
+  if (v < -1.0f || v > (float)L) return false;
+  if (v <= 0.f) v = 0.f;
+  lo = (int)v;
+  if (lo >= L - 1) { hi = lo = L - 1; v = (float)lo; } else hi = lo + 1;
+  wh = v - (float)lo;
+  wl = 1.0f - wh;
+  return true;
+}
+
+// grid: K*ph*pw blocks; block: min(256, cch rounded) threads, each 16 B of channels (loops if C is larger)
+template <typename T>
+__global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* dbg_grid, int N, int H, int W, int cch,
+                                int ph, int pw, float scale, int sampling_ratio, int aligned) {
+  int bin = blockIdx.x;
+  int j = bin % pw, i = (bin / pw) % ph, k = bin / (pw * ph);
+  RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
+  if (dbg_grid && i == 0 && j == 0 && threadIdx.x == 0) { dbg_grid[2 * k] = g.gh; dbg_grid[2 * k + 1] = g.gw; }
+  float count = (float)max(g.gh * g.gw, 1);
+  const u32x4* xb = (const u32x4*)x + (long)g.b * H * W * cch;
+  constexpr int VEC = Vec<T>::VEC;
+  for (int c = threadIdx.x; c < cch; c += blockDim.x) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g.b >= 0 && g.b < N) {
+      for (int iy = 0; iy < g.gh; ++iy) {
+        float yy = g.y0 + (float)i * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
+        int yl, yh; float wyl, wyh;
+        if (!axis_tap(yy, H, yl, yh, wyl, wyh)) continue;
+        for (int ix = 0; ix < g.gw; ++ix) {
+          float xx = g.x0 + (float)j * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+          int xl, xh; float wxl, wxh;
+          if (!axis_tap(xx, W, xl, xh, wxl, wxh)) continue;
+          float v1[8], v2[8], v3[8], v4[8];
+          Vec<T>::unpack(xb[((long)yl * W + xl) * cch + c], v1);
+          Vec<T>::unpack(xb[((long)yl * W + xh) * cch + c], v2);
+          Vec<T>::unpack(xb[((long)yh * W + xl) * cch + c], v3);
+          Vec<T>::unpack(xb[((long)yh * W + xh) * cch + c], v4);
+          float w1 = wyl * wxl, w2 = wyl * wxh, w3 = wyh * wxl, w4 = wyh * wxh;
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) acc[q] += w1 * v1[q] + w2 * v2[q] + w3 * v3[q] + w4 * v4[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] /= count;
+    ((u32x4*)y)[(long)bin * cch + c] = Vec<T>::pack(acc);
+  }
+}
+
+// Per-RoI separable weight tables: ay[k][py][bi] = (1/gh) sum_{iy in bin bi} wy(py; y_iy), likewise ax (1/gw).
+// (count = max(gh*gw,1) = gh*gw whenever any sample exists.)  Also the footprint box fp[k] = (ylo,yhi,xlo,xhi)
+// inclusive, empty when ylo > yhi.
+__global__ void k_roi_tables(const float* rois, float* ay, float* ax, int* fp, int K, int H, int W, int ph, int pw,
+                             float scale, int sampling_ratio, int aligned) {
+  int k = blockIdx.x;
+  RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
+  float* ayk = ay + (long)k * H * ph;
+  float* axk = ax + (long)k * W * pw;
+  for (int i = threadIdx.x; i < H * ph; i += blockDim.x) ayk[i] = 0.f;
+  for (int i = threadIdx.x; i < W * pw; i += blockDim.x) axk[i] = 0.f;
+  __shared__ int lim[4];
+  if (threadIdx.x == 0) { lim[0] = H; lim[1] = -1; lim[2] = W; lim[3] = -1; }
+  __syncthreads();
+  // one thread per bin per axis; bins of an axis write disjoint table columns
+  if (threadIdx.x < ph) {
+    int i = threadIdx.x, lo_min = H, hi_max = -1;
+    for (int iy = 0; iy < g.gh; ++iy) {
+      float yy = g.y0 + (float)i * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
+      int yl, yh; float wl, wh;
+      if (!axis_tap(yy, H, yl, yh, wl, wh)) continue;
+      ayk[yl * ph + i] += wl / (float)g.gh;
+      ayk[yh * ph + i] += wh / (float)g.gh;
+      lo_min = min(lo_min, yl); hi_max = max(hi_max, yh);
+    }
+    atomicMin(&lim[0], lo_min); atomicMax(&lim[1], hi_max);
+  } else if (threadIdx.x >= 64 && threadIdx.x < 64 + pw) {
+    int j = threadIdx.x - 64, lo_min = W, hi_max = -1;
+    for (int ix = 0; ix < g.gw; ++ix) {
+      float xx = g.x0 + (float)j * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+      int xl, xh; float wl, wh;
+      if (!axis_tap(xx, W, xl, xh, wl, wh)) continue;
+      axk[xl * pw + j] += wl / (float)g.gw;
+      axk[xh * pw + j] += wh / (float)g.gw;
+      lo_min = min(lo_min, xl); hi_max = max(hi_max, xh);
+    }
+    atomicMin(&lim[2], lo_min); atomicMax(&lim[3], hi_max);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool ok = g.b >= 0;
+    fp[4 * k] = ok ? lim[0] : 1; fp[4 * k + 1] = ok ? lim[1] : 0; fp[4 * k + 2] = lim[2]; fp[4 * k + 3] = lim[3];
+  }
+}
+
+// gather backward: block = one feature pixel (n, py, px); threads over channel chunks.
+// roi_start[n] .. roi_start[n+1] = the (contiguous) RoIs of image n (rois are grouped by image, as
+// convert_boxes_to_pooler_format poolers.py:68-95 emits them).
+constexpr int MAXP = 16;
+template <typename T>
+__global__ void k_roi_align_bwd(const char* dy, const float* ay, const float* ax, const int* fp, const int* roi_start,
+                                char* dx, int H, int W, int cch, int ph, int pw) {
+  long pixel = blockIdx.x;
+  int px = pixel % W, py = (pixel / W) % H, n = pixel / ((long)W * H);
+  int k0 = roi_start[n], k1 = roi_start[n + 1];
+  constexpr int VEC = Vec<T>::VEC;
+  float acc[4][8];
+  int nc = (cch + blockDim.x - 1) / blockDim.x;  // <= 4 channel chunks per thread (C*ES <= 16 KB)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[u][q] = 0.f;
+  for (int k = k0; k < k1; ++k) {
+    const int* f = fp + 4 * k;
+    if (py < f[0] || py > f[1] || px < f[2] || px > f[3]) continue;   // uniform across the block
+    const float* ayr = ay + ((long)k * H + py) * ph;
+    const float* axr = ax + ((long)k * W + px) * pw;
+    float wy[MAXP], wx[MAXP];
+    for (int i = 0; i < ph; ++i) wy[i] = ayr[i];
+    for (int j = 0; j < pw; ++j) wx[j] = axr[j];
+    for (int i = 0; i < ph; ++i) {
+      if (wy[i] == 0.f) continue;
+      for (int j = 0; j < pw; ++j) {
+        if (wx[j] == 0.f) continue;
+        float w = wy[i] * wx[j];
+        const u32x4* src = (const u32x4*)dy + (((long)k * ph + i) * pw + j) * cch;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          int c = threadIdx.x + u * blockDim.x;
+          if (u < nc && c < cch) {
+            float v[8];
+            Vec<T>::unpack(src[c], v);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[u][q] += w * v[q];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    int c = threadIdx.x + u * blockDim.x;
+    if (u < nc && c < cch) ((u32x4*)dx)[pixel * cch + c] = Vec<T>::pack(acc[u]);
+  }
+}
+
+}  // namespace
+
+extern "C" int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, int* dbg_grid, int N, int C, int H,
+                                        int W, int K, int ph, int pw, float spatial_scale, int sampling_ratio,
+                                        int aligned, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((dtype != 0 && dtype != 1) || (C * es) % 16 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || K < 0 || N < 0)
+    return CDDMSL_ERR_ARG;
+  if (K == 0) return CDDMSL_OK;   // empty inputs return correctly-shaped empties (poolers.py:221-224)
+  int cch = C * es / 16;
+  long grid = (long)K * ph * pw;
+  if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  int threads = cch >= 256 ? 256 : ((cch + 63) / 64) * 64;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0) k_roi_align_fwd<__bf16><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned);
+  else k_roi_align_fwd<float><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned);
+  return launch_status();
+}
+
+// ws_ay: K*H*ph floats, ws_ax: K*W*pw floats, ws_fp: 4*K ints; roi_start: N+1 ints (device)
+extern "C" int cddmsl_roi_align_backward(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,
+                                         float* ws_ax, int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw,
+                                         float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((dtype != 0 && dtype != 1) || (C * es) % 16 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || K < 0 || N < 0)
+    return CDDMSL_ERR_ARG;
+  if (ph > MAXP || pw > MAXP || ph > 64 || pw > 64) return CDDMSL_ERR_ARG;
+  int cch = C * es / 16;
+  if (cch > 1024) return CDDMSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) return CDDMSL_OK;
+  if (K > 0) k_roi_tables<<<dim3((unsigned)K), dim3(128), 0, st>>>(rois, ws_ay, ws_ax, ws_fp, K, H, W, ph, pw, spatial_scale, sampling_ratio, aligned);
+  long grid = (long)N * H * W;
+  if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  int threads = cch >= 256 ? 256 : ((cch + 63) / 64) * 64;
+  if (dtype == 0) k_roi_align_bwd<__bf16><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)dy, ws_ay, ws_ax, ws_fp, roi_start, (char*)dx, H, W, cch, ph, pw);
+  else k_roi_align_bwd<float><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)dy, ws_ay, ws_ax, ws_fp, roi_start, (char*)dx, H, W, cch, ph, pw);
+  return launch_status();
+}

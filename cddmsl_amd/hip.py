@@ -23,8 +23,29 @@ def _L():
         L.cddmsl_conv_fwd.argtypes = [vp] * 7 + [ci] * 16 + [vp]
         L.cddmsl_conv_wgrad.argtypes = [vp] * 4 + [ci] * 12 + [vp]
         L.cddmsl_weight_prep.argtypes = [vp] * 4 + [ci] * 5 + [vp]
-        for name in dir(L):
-            pass
+        L.cddmsl_preprocess.argtypes = [vp, vp] + [ci] * 6 + [vp, vp, ci, vp]
+        L.cddmsl_preprocess224.argtypes = [vp, vp] + [ci] * 11 + [vp, vp, ci, vp]
+        L.cddmsl_avgpool2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
+        L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
+        L.cddmsl_attn_tokens_fwd.argtypes = [vp] * 3 + [ci] * 4 + [vp]
+        L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 2 + [ci] * 4 + [vp]
+        L.cddmsl_colsum.argtypes = [vp, vp, c_long, ci, ci, ci, vp]
+        L.cddmsl_sgd_clip_step.argtypes = [vp] * 4 + [ci, vp] + [cf] * 4 + [ci, vp]
+        L.cddmsl_roi_align_forward.argtypes = [vp] * 4 + [ci] * 7 + [cf, ci, ci, ci, vp]
+        L.cddmsl_roi_align_backward.argtypes = [vp] * 7 + [ci] * 7 + [cf, ci, ci, ci, vp]
+        L.cddmsl_anchors.argtypes = [vp, vp, ci, ci, ci, cf, cf, vp]
+        L.cddmsl_sort_desc.argtypes = [vp] * 5 + [ci, ci, vp, vp, vp]
+        L.cddmsl_rpn_decode.argtypes = [vp] * 6 + [ci] * 5 + [cf] * 8 + [vp]
+        L.cddmsl_nms.argtypes = [vp] * 5 + [ci, ci, cf, ci, vp]
+        L.cddmsl_iou_match.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, cf, cf, ci, ci, ci, ci, vp]
+        L.cddmsl_attnpool_core_fwd.argtypes = [vp] * 4 + [ci, ci, ci, cf, ci, vp]
+        L.cddmsl_attnpool_core_bwd.argtypes = [vp] * 6 + [ci, ci, ci, cf, ci, vp]
+        L.cddmsl_l2norm_fwd.argtypes = [vp, vp, vp, c_long, ci, cf, vp]
+        L.cddmsl_l2norm_bwd.argtypes = [vp, vp, vp, vp, c_long, ci, vp]
+        L.cddmsl_cosine_logits_fwd.argtypes = [vp] * 4 + [c_long, ci, ci, cf, cf, vp]
+        L.cddmsl_cosine_logits_bwd.argtypes = [vp] * 5 + [c_long, ci, ci, cf, ci, vp]
+        L.cddmsl_contrastive_fwd.argtypes = [vp] * 4 + [ci, ci, vp]
+        L.cddmsl_contrastive_bwd.argtypes = [vp] * 5 + [ci, ci, vp]
         _sigs_done = True
     return L
 
@@ -98,3 +119,291 @@ def weight_prep(w_master, scale, dtype, want_fwd=True, want_dgrad=True):
     st = _L().cddmsl_weight_prep(ptr(w_master), ptr(scale), ptr(wf), ptr(wd), Cout, KH, KW, Cin, DT[dtype], stream_ptr())
     check(st, "cddmsl_weight_prep")
     return wf, wd
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def _f3(v):
+    return (c_float * 3)(*[float(x) for x in v])
+
+
+def preprocess(images_u8, Hp, Wp, mean, std, dtype, Cp=None):
+    """list of u8 CHW device tensors -> normalised, zero-padded NHWC [N,Hp,Wp,Cp] (rcnn.py:758-768)."""
+    require_cuda(*images_u8)
+    Cp = Cp or (8 if dtype == torch.bfloat16 else 4)
+    out = torch.empty((len(images_u8), Hp, Wp, Cp), device=images_u8[0].device, dtype=dtype)
+    m, s = _f3(mean), _f3(std)
+    for n, im in enumerate(images_u8):
+        assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 and im.is_contiguous()
+        check(_L().cddmsl_preprocess(ptr(im), ptr(out), n, im.shape[1], im.shape[2], Hp, Wp, Cp, m, s, DT[dtype], stream_ptr()),
+              "cddmsl_preprocess")
+    return out
+
+
+def preprocess224(images_u8, Hp, Wp, mean, std, dtype, size=224, Cp=None):
+    """rcnn.py:161-179: /255 -> pad to (Hp,Wp) -> bicubic short side `size` -> center crop -> normalise; NHWC out."""
+    require_cuda(*images_u8)
+    Cp = Cp or (8 if dtype == torch.bfloat16 else 4)
+    if Wp <= Hp:
+        RW, RH = size, int(size * Hp / Wp)
+    else:
+        RH, RW = size, int(size * Wp / Hp)
+    top, left = int(round((RH - size) / 2.0)), int(round((RW - size) / 2.0))
+    out = torch.empty((len(images_u8), size, size, Cp), device=images_u8[0].device, dtype=dtype)
+    m, s = _f3(mean), _f3(std)
+    for n, im in enumerate(images_u8):
+        assert im.dtype == torch.uint8 and im.is_contiguous()
+        check(_L().cddmsl_preprocess224(ptr(im), ptr(out), n, im.shape[1], im.shape[2], Hp, Wp, RH, RW, top, left, size, Cp,
+                                         m, s, DT[dtype], stream_ptr()), "cddmsl_preprocess224")
+    return out
+
+
+def avgpool2_fwd(x):
+    require_cuda(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
+    check(_L().cddmsl_avgpool2_fwd(ptr(x), ptr(y), N, H, W, C, _dt(x), stream_ptr()), "cddmsl_avgpool2_fwd")
+    return y
+
+
+def avgpool2_bwd(dy, in_shape, mask=None, add=None):
+    """dx = up(dy)/4 (+ add), zeroed where mask <= 0.  in_shape = (N,H,W,C) of the pooled tensor's input."""
+    require_cuda(dy, mask, add)
+    N, H, W, C = in_shape
+    assert dy.is_contiguous() and tuple(dy.shape) == (N, H // 2, W // 2, C)
+    dx = torch.empty(in_shape, device=dy.device, dtype=dy.dtype)
+    check(_L().cddmsl_avgpool2_bwd(ptr(dy), ptr(mask), ptr(add), ptr(dx), N, H, W, C, _dt(dy), stream_ptr()), "cddmsl_avgpool2_bwd")
+    return dx
+
+
+def attn_tokens_fwd(x, pos):
+    """x [K,P,C] (T), pos [P+1,C] f32 -> tok [K,P+1,C]"""
+    require_cuda(x, pos)
+    K, P, C = x.shape
+    assert pos.dtype == torch.float32 and tuple(pos.shape) == (P + 1, C) and x.is_contiguous() and pos.is_contiguous()
+    tok = torch.empty((K, P + 1, C), device=x.device, dtype=x.dtype)
+    check(_L().cddmsl_attn_tokens_fwd(ptr(x), ptr(pos), ptr(tok), K, P, C, _dt(x), stream_ptr()), "cddmsl_attn_tokens_fwd")
+    return tok
+
+
+def attn_tokens_bwd(dtok):
+    require_cuda(dtok)
+    K, P1, C = dtok.shape
+    dx = torch.empty((K, P1 - 1, C), device=dtok.device, dtype=dtok.dtype)
+    check(_L().cddmsl_attn_tokens_bwd(ptr(dtok), ptr(dx), K, P1 - 1, C, _dt(dtok), stream_ptr()), "cddmsl_attn_tokens_bwd")
+    return dx
+
+
+def colsum(x2d, period=1, out=None):
+    """f32 column sums of x [rows, cols] (rows folded modulo `period`)."""
+    require_cuda(x2d, out)
+    rows, cols = x2d.shape
+    assert x2d.is_contiguous()
+    if out is None:
+        out = torch.zeros((period, cols) if period > 1 else (cols,), device=x2d.device, dtype=torch.float32)
+    check(_L().cddmsl_colsum(ptr(x2d), ptr(out), rows, cols, period, _dt(x2d), stream_ptr()), "cddmsl_colsum")
+    return out
+
+
+def sgd_clip_step(params, grads, moms, norm_ws, lr, momentum, wd, clip, first_step):
+    """Fused per-parameter grad-norm clip + SGD(momentum, wd) over a list of f32 tensors (solver/build.py:59-130)."""
+    n = len(params)
+    if n == 0:
+        return
+    require_cuda(*params, *grads, *moms)
+    for p, g, m in zip(params, grads, moms):
+        assert p.dtype == g.dtype == m.dtype == torch.float32
+        assert p.stride() == g.stride() == m.stride(), "param/grad/momentum must share a memory layout"
+    P = (c_void_p * n)(*[p.data_ptr() for p in params])
+    G = (c_void_p * n)(*[g.data_ptr() for g in grads])
+    M = (c_void_p * n)(*[m.data_ptr() for m in moms])
+    S = (c_long * n)(*[p.numel() for p in params])
+    check(_L().cddmsl_sgd_clip_step(P, G, M, S, n, ptr(norm_ws), lr, momentum, wd, clip, int(first_step), stream_ptr()),
+          "cddmsl_sgd_clip_step")
+
+
+# ------------------------------------------------------------------------------------------------ RoIAlign
+def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, dbg_grid=None):
+    """x NHWC [N,H,W,C]; rois [K,5] f32 (batch_idx,x0,y0,x1,y1) -> [K,ph,pw,C]  (layers/roi_align.py:49-65)."""
+    require_cuda(x, rois)
+    assert rois.dim() == 2 and rois.size(1) == 5 and rois.dtype == torch.float32 and rois.is_contiguous()
+    N, H, W, C = x.shape
+    K = rois.shape[0]
+    y = torch.empty((K, ph, pw, C), device=x.device, dtype=x.dtype)
+    check(_L().cddmsl_roi_align_forward(ptr(x), ptr(rois), ptr(y), ptr(dbg_grid), N, C, H, W, K, ph, pw, spatial_scale,
+                                         sampling_ratio, int(aligned), _dt(x), stream_ptr()), "cddmsl_roi_align_forward")
+    return y
+
+
+def roi_align_backward(dy, rois, roi_start, in_shape, spatial_scale, sampling_ratio, aligned):
+    """dy [K,ph,pw,C] -> dx NHWC in_shape.  rois must be grouped by image; roi_start int32 [N+1] prefix offsets."""
+    require_cuda(dy, rois, roi_start)
+    N, H, W, C = in_shape
+    K, ph, pw, _ = dy.shape
+    assert roi_start.dtype == torch.int32 and roi_start.numel() == N + 1 and dy.is_contiguous()
+    dx = torch.empty(in_shape, device=dy.device, dtype=dy.dtype)
+    ay = torch.empty(max(K, 1) * H * ph, device=dy.device, dtype=torch.float32)
+    ax = torch.empty(max(K, 1) * W * pw, device=dy.device, dtype=torch.float32)
+    fp = torch.empty(max(K, 1) * 4, device=dy.device, dtype=torch.int32)
+    check(_L().cddmsl_roi_align_backward(ptr(dy), ptr(rois), ptr(roi_start), ptr(dx), ptr(ay), ptr(ax), ptr(fp), N, C, H, W, K,
+                                          ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(dy), stream_ptr()),
+          "cddmsl_roi_align_backward")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ boxes
+def anchors(cell, Hf, Wf, stride, offset):
+    require_cuda(cell)
+    A = cell.shape[0]
+    out = torch.empty((Hf * Wf * A, 4), device=cell.device, dtype=torch.float32)
+    check(_L().cddmsl_anchors(ptr(cell), ptr(out), Hf, Wf, A, stride, offset, stream_ptr()), "cddmsl_anchors")
+    return out
+
+
+_sort_ws = {}
+
+
+def sort_desc(keys):
+    """Stable descending sort of each row of keys [N,total] f32 -> (sorted keys, int32 order)."""
+    require_cuda(keys)
+    N, total = keys.shape
+    assert keys.dtype == torch.float32 and keys.is_contiguous()
+    dev = keys.device
+    offs = torch.arange(0, (N + 1) * total, total, device=dev, dtype=torch.int32)
+    keys_out = torch.empty_like(keys)
+    idx = torch.empty((N, total), device=dev, dtype=torch.int32)
+    order = torch.empty((N, total), device=dev, dtype=torch.int32)
+    nbytes = ctypes.c_size_t(0)
+    check(_L().cddmsl_sort_desc(ptr(keys), ptr(keys_out), ptr(idx), ptr(order), ptr(offs), N, total, None, ctypes.byref(nbytes),
+                                stream_ptr()), "cddmsl_sort_desc(size)")
+    ws = torch.empty(max(int(nbytes.value), 16), device=dev, dtype=torch.uint8)
+    check(_L().cddmsl_sort_desc(ptr(keys), ptr(keys_out), ptr(idx), ptr(order), ptr(offs), N, total, ptr(ws), ctypes.byref(nbytes),
+                                stream_ptr()), "cddmsl_sort_desc")
+    return keys_out, order
+
+
+def rpn_decode(order, deltas, cell, img_hw, Hf, Wf, topk, stride, offset, weights, scale_clamp, min_size):
+    """Decode + clip the top-k sorted anchors of every image -> boxes [N,topk,4] f32, valid u8 [N,topk]."""
+    require_cuda(order, deltas, cell, img_hw)
+    N = deltas.shape[0]
+    A = cell.shape[0]
+    assert deltas.dtype == torch.float32 and deltas.is_contiguous() and img_hw.dtype == torch.int32
+    boxes = torch.empty((N, topk, 4), device=deltas.device, dtype=torch.float32)
+    valid = torch.empty((N, topk), device=deltas.device, dtype=torch.uint8)
+    check(_L().cddmsl_rpn_decode(ptr(order), ptr(deltas), ptr(cell), ptr(img_hw), ptr(boxes), ptr(valid), N, Hf, Wf, A, topk,
+                                  stride, offset, *[float(w) for w in weights], scale_clamp, min_size, stream_ptr()),
+          "cddmsl_rpn_decode")
+    return boxes, valid
+
+
+def nms(boxes, valid, thr, max_keep):
+    """boxes [N,n,4] f32 score-descending, valid u8 [N,n] -> keep int32 [N,max_keep] (positions), nkeep int32 [N]."""
+    require_cuda(boxes, valid)
+    N, n, _ = boxes.shape
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and valid.dtype == torch.uint8 and valid.is_contiguous()
+    nw = (n + 63) // 64
+    mask = torch.empty(max(N * n * nw, 1), device=boxes.device, dtype=torch.int64)
+    keep = torch.full((N, max_keep), -1, device=boxes.device, dtype=torch.int32)
+    nkeep = torch.zeros(N, device=boxes.device, dtype=torch.int32)
+    check(_L().cddmsl_nms(ptr(boxes), ptr(valid), ptr(mask), ptr(keep), ptr(nkeep), N, n, thr, max_keep, stream_ptr()), "cddmsl_nms")
+    return keep, nkeep
+
+
+def iou_match(gt, preds, thresholds, labels, allow_low_quality):
+    """Fused pairwise_iou + Matcher for one image: gt [G,4], preds [P,4] -> (matches int64 [P], labels int8 [P])."""
+    require_cuda(gt, preds)
+    G, P = gt.shape[0], preds.shape[0]
+    assert gt.dtype == preds.dtype == torch.float32 and gt.is_contiguous() and preds.is_contiguous()
+    matches = torch.empty(P, device=preds.device, dtype=torch.int64)
+    lab = torch.empty(P, device=preds.device, dtype=torch.int8)
+    best = torch.empty(max(G, 1), device=preds.device, dtype=torch.int32)
+    nthr = len(thresholds)
+    t0 = float(thresholds[0])
+    t1 = float(thresholds[1]) if nthr > 1 else 0.0
+    l = list(labels) + [0]
+    check(_L().cddmsl_iou_match(ptr(gt), G, ptr(preds), P, ptr(matches), ptr(lab), ptr(best), nthr, t0, t1, l[0], l[1], l[2],
+                                 int(allow_low_quality), stream_ptr()), "cddmsl_iou_match")
+    return matches, lab
+
+
+# ------------------------------------------------------------------------------------------------ attention pool / losses
+def attnpool_core_fwd(q0, kv, heads):
+    require_cuda(q0, kv)
+    K, C = q0.shape
+    T = kv.shape[1]
+    assert kv.shape == (K, T, 2 * C) and C == heads * 64 and q0.is_contiguous() and kv.is_contiguous()
+    o = torch.empty((K, C), device=q0.device, dtype=q0.dtype)
+    p = torch.empty((K, heads, T), device=q0.device, dtype=torch.float32)
+    check(_L().cddmsl_attnpool_core_fwd(ptr(q0), ptr(kv), ptr(o), ptr(p), K, T, heads, 64 ** -0.5, _dt(q0), stream_ptr()),
+          "cddmsl_attnpool_core_fwd")
+    return o, p
+
+
+def attnpool_core_bwd(dO, q0, kv, p, heads):
+    require_cuda(dO, q0, kv, p)
+    K, C = q0.shape
+    T = kv.shape[1]
+    dq0 = torch.empty_like(q0)
+    dkv = torch.empty_like(kv)
+    check(_L().cddmsl_attnpool_core_bwd(ptr(dO.contiguous()), ptr(q0), ptr(kv), ptr(p), ptr(dq0), ptr(dkv), K, T, heads, 64 ** -0.5,
+                                         _dt(q0), stream_ptr()), "cddmsl_attnpool_core_bwd")
+    return dq0, dkv
+
+
+def l2norm_fwd(x, eps):
+    require_cuda(x)
+    R, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty_like(x)
+    inv = torch.empty(R, device=x.device, dtype=torch.float32)
+    check(_L().cddmsl_l2norm_fwd(ptr(x), ptr(y), ptr(inv), R, D, eps, stream_ptr()), "cddmsl_l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    require_cuda(dy, y, inv)
+    dx = torch.empty_like(y)
+    check(_L().cddmsl_l2norm_bwd(ptr(dy.contiguous()), ptr(y), ptr(inv), ptr(dx), y.shape[0], y.shape[1], stream_ptr()), "cddmsl_l2norm_bwd")
+    return dx
+
+
+def cosine_logits_fwd(x, wn, temperature, eps=1e-12):
+    require_cuda(x, wn)
+    R, D = x.shape
+    Kc = wn.shape[0]
+    assert x.dtype == wn.dtype == torch.float32 and x.is_contiguous() and wn.is_contiguous()
+    scores = torch.empty((R, Kc + 1), device=x.device, dtype=torch.float32)
+    inv = torch.empty(R, device=x.device, dtype=torch.float32)
+    check(_L().cddmsl_cosine_logits_fwd(ptr(x), ptr(wn), ptr(scores), ptr(inv), R, D, Kc, temperature, eps, stream_ptr()),
+          "cddmsl_cosine_logits_fwd")
+    return scores, inv
+
+
+def cosine_logits_bwd(ds, x, wn, inv, temperature, dx=None):
+    require_cuda(ds, x, wn, inv, dx)
+    R, D = x.shape
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    check(_L().cddmsl_cosine_logits_bwd(ptr(ds.contiguous()), ptr(x), ptr(wn), ptr(inv), ptr(dx), R, D, wn.shape[0], temperature, int(acc),
+                                         stream_ptr()), "cddmsl_cosine_logits_bwd")
+    return dx
+
+
+def contrastive_fwd(S):
+    require_cuda(S)
+    n = S.shape[0]
+    assert S.dtype == torch.float32 and S.shape == (n, n) and S.is_contiguous()
+    rl = torch.empty(n, device=S.device, dtype=torch.float32)
+    cl = torch.empty(n, device=S.device, dtype=torch.float32)
+    loss = torch.empty(1, device=S.device, dtype=torch.float32)
+    check(_L().cddmsl_contrastive_fwd(ptr(S), ptr(rl), ptr(cl), ptr(loss), n, n, stream_ptr()), "cddmsl_contrastive_fwd")
+    return loss, rl, cl
+
+
+def contrastive_bwd(S, rl, cl, gloss):
+    require_cuda(S, rl, cl, gloss)
+    n = S.shape[0]
+    dS = torch.empty_like(S)
+    check(_L().cddmsl_contrastive_bwd(ptr(S), ptr(rl), ptr(cl), ptr(gloss.reshape(1).float().contiguous()), ptr(dS), n, n, stream_ptr()),
+          "cddmsl_contrastive_bwd")
+    return dS

@@ -1,0 +1,240 @@
+"""GPU parity (through the C-ABI) of the non-GEMM hot-path kernels against the CPU oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+T = torch.tensor
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------ RoIAlign
+@pytest.mark.parametrize("aligned", [False, True])
+def test_roi_align_kat(aligned):
+    """tests/layers/test_roi_align.py:14-47 table, through the HIP kernel (C padded 1 -> 4 channels)."""
+    from cddmsl_amd import hip
+    k = json.load(open(os.path.join(G, "kat.json")))["roi_align_5x5"]
+    x = torch.arange(25, dtype=torch.float32).reshape(1, 5, 5, 1).repeat(1, 1, 1, 4).cuda()
+    rois = T([[0.0] + [float(v) for v in k["box"]]]).cuda()
+    out = hip.roi_align_forward(x, rois, 4, 4, 1.0, 0, aligned)
+    exp = T(k["aligned_true" if aligned else "aligned_false"])
+    assert torch.allclose(out[0, :, :, 0].cpu(), exp)
+
+
+def test_roi_align_empty():
+    from cddmsl_amd import hip
+    x = torch.rand(1, 5, 5, 4).cuda()
+    out = hip.roi_align_forward(x, T([[0.0, 3.0, 3.0, 3.0, 3.0]]).cuda(), 7, 7, 1.0, 0, True)
+    assert out.shape == (1, 7, 7, 4) and (out == 0).all()
+    assert hip.roi_align_forward(x, torch.zeros(0, 5).cuda(), 7, 7, 1.0, 0, True).shape == (0, 7, 7, 4)
+    dx = hip.roi_align_backward(torch.ones(1, 7, 7, 4).cuda(), T([[0.0, 3.0, 3.0, 3.0, 3.0]]).cuda(),
+                                T([0, 1], dtype=torch.int32).cuda(), (1, 5, 5, 4), 1.0, 0, True)
+    assert (dx == 0).all()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
+def test_roi_align_vs_oracle(dtype, tol):
+    from cddmsl_amd import hip
+    from oracle import ops as oo
+    N, C, H, W, K = 3, 64, 13, 21, 40
+    g = torch.Generator().manual_seed(7)
+    x = _rand((N, C, H, W), 1).to(dtype).float()
+    b = torch.sort(torch.randint(0, N, (K,), generator=g)).values
+    x0 = torch.rand(K, generator=g) * W * 16 * 0.9 - 10
+    y0 = torch.rand(K, generator=g) * H * 16 * 0.9 - 10
+    rois = torch.stack([b.float(), x0, y0, x0 + torch.rand(K, generator=g) * W * 12, y0 + torch.rand(K, generator=g) * H * 12], 1)
+    rois[5, 3:] = rois[5, 1:3]  # empty box
+    xr = x.clone().requires_grad_(True)
+    ref = oo.roi_align(xr, rois, 14, 1 / 16, 0, True)
+    dy = _rand(tuple(ref.shape), 3).to(dtype).float()
+    ref.backward(dy)
+    dbg = torch.zeros(K, 2, dtype=torch.int32).cuda()
+    out = hip.roi_align_forward(_nhwc(x).cuda().to(dtype), rois.cuda(), 14, 14, 1 / 16, 0, True, dbg)
+    assert (out.float().cpu().permute(0, 3, 1, 2) - ref.detach()).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    # bit-exact integer sample-grid assignment (ceil(roi/14) per axis)
+    rh = (rois[:, 4] * (1 / 16) - 0.5) - (rois[:, 2] * (1 / 16) - 0.5)
+    rw = (rois[:, 3] * (1 / 16) - 0.5) - (rois[:, 1] * (1 / 16) - 0.5)
+    assert torch.equal(dbg.cpu()[:, 0], torch.ceil(rh / 14).int()) and torch.equal(dbg.cpu()[:, 1], torch.ceil(rw / 14).int())
+    start = torch.searchsorted(b, torch.arange(N + 1)).int().cuda()
+    dx = hip.roi_align_backward(_nhwc(dy).cuda().to(dtype), rois.cuda(), start, (N, H, W, C), 1 / 16, 0, True)
+    assert (_nchw(dx.float().cpu()) - xr.grad).abs().max() < tol * max(1.0, float(xr.grad.abs().max()))
+
+
+# ------------------------------------------------------------------ preprocess / pooling
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_preprocess(dtype, tol):
+    from cddmsl_amd import hip
+    from oracle import model as om
+    cfg = om.Cfg()
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.randint(0, 256, (3, 37, 53), generator=g, dtype=torch.uint8), torch.randint(0, 256, (3, 41, 49), generator=g, dtype=torch.uint8)]
+    ref, sizes = om.preprocess_image(cfg, [{"image": i} for i in imgs])
+    out = hip.preprocess([i.cuda() for i in imgs], 41, 53, cfg.pixel_mean, cfg.pixel_std, dtype)
+    assert (out[..., :3].float().cpu().permute(0, 3, 1, 2) - ref).abs().max() < tol * 3
+    assert (out[..., 3:] == 0).all()
+    ref2 = om.preprocess_image_train(cfg, [{"image": i} for i in imgs], "image")
+    # torchvision Resize is un-vendored: bicubic definition = ATen upsample_bicubic2d(align_corners=False) ("parity unpinned")
+    imgs2 = [torch.randint(0, 256, (3, 260, 300), generator=g, dtype=torch.uint8), torch.randint(0, 256, (3, 250, 330), generator=g, dtype=torch.uint8)]
+    ref2 = om.preprocess_image_train(cfg, [{"image": i} for i in imgs2], "image")
+    out2 = hip.preprocess224([i.cuda() for i in imgs2], 260, 330, cfg.pixel_mean, cfg.pixel_std, dtype)
+    assert out2.shape[:3] == (2, 224, 224)
+    assert (out2[..., :3].float().cpu().permute(0, 3, 1, 2) - ref2).abs().max() < max(tol * 5, 2e-5)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_avgpool(dtype, tol):
+    from cddmsl_amd import hip
+    x = _rand((2, 16, 9, 11), 5).to(dtype).float()
+    y = hip.avgpool2_fwd(_nhwc(x).cuda().to(dtype))
+    assert (_nchw(y.float().cpu()) - F.avg_pool2d(x, 2)).abs().max() < tol
+    xr = x.clone().requires_grad_(True)
+    out = F.relu(xr)
+    dy = _rand((2, 16, 4, 5), 6).to(dtype).float()
+    add = _rand((2, 16, 9, 11), 7).to(dtype).float()
+    F.avg_pool2d(out, 2).backward(dy)
+    # dx = (up(dy)/4 + add) * (x > 0)
+    dx = hip.avgpool2_bwd(_nhwc(dy).cuda().to(dtype), (2, 9, 11, 16), _nhwc(x).cuda().to(dtype), _nhwc(add).cuda().to(dtype))
+    ref = xr.grad + add * (x > 0)
+    assert (_nchw(dx.float().cpu()) - ref).abs().max() < tol * 4
+
+
+# ------------------------------------------------------------------ boxes: bit-exact integer stages
+def test_anchors_iou_match_bitexact():
+    from cddmsl_amd import hip
+    from oracle import ops as oo
+    cell = oo.cell_anchors()
+    a_ref = oo.grid_anchors(7, 11, 16)
+    a = hip.anchors(cell.cuda(), 7, 11, 16.0, 0.0)
+    assert torch.equal(a.cpu(), a_ref)
+    g = np.load(os.path.join(G, "ref_boxes.npz"))
+    gt, pr = T(g["gt"]), T(g["pr"])
+    m1, l1 = hip.iou_match(gt.cuda(), pr.cuda(), [0.3, 0.7], [0, -1, 1], True)
+    m2, l2 = hip.iou_match(gt.cuda(), pr.cuda(), [0.5], [0, 1], False)
+    assert np.array_equal(m1.cpu().numpy(), g["match_rpn"]) and np.array_equal(l1.cpu().numpy(), g["label_rpn"])
+    assert np.array_equal(m2.cpu().numpy(), g["match_roi"]) and np.array_equal(l2.cpu().numpy(), g["label_roi"])
+    # larger random case vs oracle, incl. empty gt
+    gen = torch.Generator().manual_seed(9)
+    gt2 = torch.rand(7, 4, generator=gen) * 600
+    gt2[:, 2:] = gt2[:, :2] + 30 + torch.rand(7, 2, generator=gen) * 300
+    an = oo.grid_anchors(50, 83, 16)
+    mo, lo = oo.matcher(oo.pairwise_iou(gt2, an), [0.3, 0.7], [0, -1, 1], True)
+    mg, lg = hip.iou_match(gt2.cuda(), an.cuda(), [0.3, 0.7], [0, -1, 1], True)
+    assert torch.equal(mg.cpu(), mo) and torch.equal(lg.cpu(), lo)
+    me, le = hip.iou_match(torch.zeros(0, 4).cuda(), an[:100].cuda(), [0.3, 0.7], [0, -1, 1], True)
+    assert (me == 0).all() and (le == 0).all()
+
+
+def test_sort_decode_nms_bitexact():
+    from cddmsl_amd import hip
+    from oracle import ops as oo
+    from oracle import model as om
+    cfg = om.Cfg()
+    N, Hf, Wf, A = 2, 12, 17, 15
+    total = Hf * Wf * A
+    logits = _rand((N, total), 1)
+    logits[0, 5] = logits[0, 900]  # tie -> lower index first
+    deltas = _rand((N, total, 4), 2, 0.4)
+    deltas[1, 3, 2] = 50.0  # scale clamp
+    sizes = [(180, 260), (192, 272)]
+    anchors = oo.grid_anchors(Hf, Wf, 16)
+    topk = 1000
+    prop = oo.apply_deltas(deltas.reshape(-1, 4), anchors.unsqueeze(0).expand(N, -1, -1).reshape(-1, 4), cfg.rpn_bbox_weights).view(N, -1, 4)
+    cfg2 = om.Cfg(rpn_pre_nms_topk=topk, rpn_post_nms_topk=300)
+    rec = {}
+    ref = om.find_top_rpn_proposals(cfg2, prop, logits, sizes, True, rec)
+
+    keys, order = hip.sort_desc(logits.cuda())
+    srt = torch.sort(logits, descending=True, dim=1, stable=True)
+    assert torch.equal(order.cpu().long(), srt.indices) and torch.equal(keys.cpu(), srt.values)
+    img_hw = T(sizes, dtype=torch.int32).cuda()
+    boxes, valid = hip.rpn_decode(order, deltas.cuda(), oo.cell_anchors().cuda(), img_hw, Hf, Wf, topk, 16.0, 0.0,
+                                  cfg.rpn_bbox_weights, oo.SCALE_CLAMP, 0.0)
+    # decode is fp32 with expf: compare to the oracle's boxes within 1e-4 px, then NMS on the ORACLE's boxes bit-exactly
+    for n in range(N):
+        ob = oo.clip_boxes(prop[n][srt.indices[n, :topk]], sizes[n])
+        assert (boxes[n].cpu() - ob).abs().max() < 2e-3
+        assert torch.equal(valid[n].cpu() == 1, oo.nonempty(ob))
+    oboxes = torch.stack([oo.clip_boxes(prop[n][srt.indices[n, :topk]], sizes[n]) for n in range(N)]).cuda()
+    ovalid = torch.stack([oo.nonempty(oo.clip_boxes(prop[n][srt.indices[n, :topk]], sizes[n])) for n in range(N)]).to(torch.uint8).cuda()
+    keep, nkeep = hip.nms(oboxes, ovalid, 0.7, 300)
+    for n in range(N):
+        # oracle keep indexes the nonempty-filtered list; map positions in the sorted list through the filter
+        pos = torch.nonzero(ovalid[n].cpu() == 1, as_tuple=True)[0]
+        assert int(nkeep[n]) == len(rec["nms_keep"][n])
+        assert torch.equal(keep[n, : int(nkeep[n])].cpu().long(), pos[rec["nms_keep"][n]])
+
+
+# ------------------------------------------------------------------ losses
+def test_cosine_logits_and_contrastive():
+    from cddmsl_amd import hip, synthetic
+    from oracle import model as om
+    cfg = om.Cfg()
+    sd = synthetic.make_state_dict(0)
+    x = _rand((37, 1024), 1).requires_grad_(True)
+    scores, _ = om.box_predictor(sd, cfg, x)
+    ds = _rand(tuple(scores.shape), 2)
+    scores.backward(ds)
+    # bbox_pred path excluded: zero its contribution
+    x2 = x.detach().clone().requires_grad_(True)
+    nx = F.normalize(x2, dim=1)
+    s2 = torch.cat((nx @ F.normalize(sd["roi_heads.box_predictor.cls_score.weight"], dim=1).t(), nx @ torch.zeros(1024, 1)), 1) / cfg.cls_temp
+    s2.backward(ds)
+    wn = F.normalize(sd["roi_heads.box_predictor.cls_score.weight"], dim=1).cuda()
+    sg, inv = hip.cosine_logits_fwd(x.detach().cuda(), wn, cfg.cls_temp)
+    assert (sg.cpu() - s2.detach()).abs().max() < 1e-4 * float(s2.abs().max())
+    assert (sg[:, -1] == 0).all()
+    dx = hip.cosine_logits_bwd(ds.cuda(), x.detach().cuda(), wn, inv, cfg.cls_temp)
+    assert (dx.cpu() - x2.grad).abs().max() < 1e-4 * float(x2.grad.abs().max())
+
+    a = _rand((48, 256), 3).requires_grad_(True)
+    b = _rand((48, 256), 4).requires_grad_(True)
+    loss = om.symmetric_ce(a, b)
+    loss.backward()
+    an, ia = hip.l2norm_fwd(a.detach().cuda(), 0.0)
+    bn, ib = hip.l2norm_fwd(b.detach().cuda(), 0.0)
+    S = hip.linear_fwd(an, bn)
+    lg, rl, cl = hip.contrastive_fwd(S)
+    assert abs(float(lg) - float(loss)) < 1e-5 * abs(float(loss))
+    dS = hip.contrastive_bwd(S, rl, cl, torch.ones(1).cuda())
+    dan = hip.linear_fwd(dS, bn.t().contiguous())
+    dbn = hip.linear_fwd(dS.t().contiguous(), an.t().contiguous())
+    da = hip.l2norm_bwd(dan, an, ia)
+    db = hip.l2norm_bwd(dbn, bn, ib)
+    assert (da.cpu() - a.grad).abs().max() < 1e-4 * float(a.grad.abs().max())
+    assert (db.cpu() - b.grad).abs().max() < 1e-4 * float(b.grad.abs().max())
+
+
+def test_sgd_clip_step():
+    from cddmsl_amd import hip
+    from oracle import model as om
+    cfg = om.Cfg()
+    shapes = [(64, 3, 3, 32), (1000,), (7, 5), (2048, 1, 1, 512)]
+    ps = [_rand(s, i) for i, s in enumerate(shapes)]
+    gs = [_rand(s, 10 + i, 3.0 if i % 2 else 0.01) for i, s in enumerate(shapes)]
+    sd = {str(i): p.clone() for i, p in enumerate(ps)}
+    mom = {}
+    P = [p.clone().cuda() for p in ps]
+    M = [torch.zeros_like(p) for p in P]
+    ws = torch.zeros(len(P)).cuda()
+    for it in (150, 151):
+        lr = om.sgd_step(sd, {str(i): g for i, g in enumerate(gs)}, mom, cfg, it)
+        hip.sgd_clip_step(P, [g.cuda() for g in gs], M, ws, lr, cfg.momentum, cfg.weight_decay, cfg.clip_value, it == 150)
+    for i in range(len(ps)):
+        assert (P[i].cpu() - sd[str(i)]).abs().max() < 1e-6
+        assert (M[i].cpu() - mom[str(i)]).abs().max() < 1e-5
