@@ -187,6 +187,22 @@ __global__ void k_attn_tokens_bwd(const char* dtok, char* dx, int K, int P, int 
   }
 }
 
+// ReLU backward: dx = g where y > 0 else 0 (optionally g given in f32 while y/dx are T)
+template <typename T>
+__global__ void k_relu_bwd(const char* g, const char* y, char* dx, long nchunks, int g_f32) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    float a[8], m[8], o[8];
+    Elt<T>::unpack(((const u32x4*)y)[i], m);
+    if (g_f32 && Elt<T>::VEC == 8) {
+      Elt<float>::unpack(((const u32x4*)g)[2 * i], a);
+      Elt<float>::unpack(((const u32x4*)g)[2 * i + 1], a + 4);
+    } else Elt<T>::unpack(((const u32x4*)g)[i], a);
+#pragma unroll
+    for (int j = 0; j < Elt<T>::VEC; ++j) o[j] = m[j] > 0.f ? a[j] : 0.f;
+    ((u32x4*)dx)[i] = Elt<T>::pack(o);
+  }
+}
+
 // column sums: out[c] (f32) += sum_r x[r][c]  (bias grads, positional-embedding grads with row period)
 template <typename T>
 __global__ void k_colsum(const char* x, float* out, long rows, int cols, int period) {
@@ -311,6 +327,15 @@ extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, 
   long total = (long)K * P * cch;
   if (total == 0) return CDDMSL_OK;
   DISPATCH(dtype, k_attn_tokens_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (char*)dx, K, P, cch));
+  return launch_status();
+}
+
+extern "C" int cddmsl_relu_bwd(const void* g, const void* y, void* dx, long numel, int g_f32, int dtype, void* stream) {
+  int vec = dtype == 0 ? 8 : 4;
+  if (numel < 0 || numel % vec) return CDDMSL_ERR_ARG;
+  if (numel == 0) return CDDMSL_OK;
+  long nch = numel / vec;
+  DISPATCH(dtype, k_relu_bwd, <<<dim3(gsz(nch)), dim3(256), 0, (hipStream_t)stream>>>((const char*)g, (const char*)y, (char*)dx, nch, g_f32));
   return launch_status();
 }
 

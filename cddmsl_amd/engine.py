@@ -1,0 +1,185 @@
+"""Training loop of the hot path -- detectron2/engine/train_loop.py:261-431 (``SimpleTrainer``), engine/defaults.py:60-79
+(DDP), engine/launch.py:27-125 (one process per GPU).
+
+``SimpleTrainer.run_step`` keeps the reference's sequence: supervised forward, caption-consistency forward (x0 during
+burn-in, iter <= 10000), region-level forward after burn-in, ``sum(losses).backward()``, gradient all-reduce (mean) over
+RCCL/xGMI, per-parameter clip + SGD.  Differences that do not change results: world_size 1 runs without a process
+group; the per-iteration ``.item()`` sync of ``_write_metrics`` only happens every ``metrics_period`` steps.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from .modeling.clipcap import TransformerMapper
+from .hip import same_layout
+from .solver import build_optimizer
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def init_distributed(backend=None):
+    """engine/launch.py:98-123 equivalent under torchrun (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+    return get_rank(), get_world_size()
+
+
+class GradBuckets:
+    """DDP-style gradient averaging (engine/defaults.py:74): all trainable grads live in one flat f32 buffer
+    (each ``p.grad`` is a view with the parameter's memory layout), all-reduced in a few large RCCL calls --
+    xGMI rings are per-link bound, so few big messages beat DDP's 25 MB default buckets."""
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            chunk = self.flat[off:off + n]
+            if p.dim() == 4:   # channels_last OIHW parameter -> grad with the same strides
+                co, ci, kh, kw = p.shape
+                g = chunk.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+            else:
+                g = chunk.view(p.shape)
+            assert same_layout(g, p), (g.stride(), p.stride(), p.shape)
+            p.grad = g
+            off += n
+        per = max(bucket_bytes // 4, 1)
+        self.buckets = [self.flat[i:i + per] for i in range(0, total, per)]
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        ws = get_world_size()
+        if ws == 1:
+            return
+        self.flat.mul_(1.0 / ws)
+        handles = [dist.all_reduce(b, async_op=True) for b in self.buckets]
+        for h in handles:
+            h.wait()
+
+
+class SimpleTrainer:
+    def __init__(self, model, data_loader, optimizer, cfg, clipcap_model=None, metrics_period=20):
+        model.train()
+        self.model, self.cfg = model, cfg
+        if clipcap_model is None:   # train_loop.py:281-288: ClipCaptionModel(40, 40).clip_project, frozen
+            clipcap_model = TransformerMapper(1024, 768, 40, 40, 8, compute_dtype=model.compute_dtype)
+            path = cfg.MODEL.get("VISION_TO_LANG_PATH", "")
+            if path and os.path.exists(path):
+                sd = torch.load(path, map_location="cpu", weights_only=True)
+                clipcap_model.load_state_dict({k[len("clip_project."):]: v for k, v in sd.items() if k.startswith("clip_project.")})
+            clipcap_model.to(model.device)
+        self.clipcap_model = clipcap_model.eval()
+        for p in self.clipcap_model.parameters():
+            p.requires_grad = False
+        self.data_loader = data_loader
+        self._data_loader_iter = iter(data_loader)
+        self.optimizer = optimizer
+        self.buckets = GradBuckets(optimizer.params)
+        self.iter = 0
+        self.burn_in = 10000            # train_loop.py:334
+        self.metrics_period = metrics_period
+        self.storage = {}
+
+    def compute_losses(self, data):
+        """train_loop.py:331-365"""
+        kd = self.cfg.MODEL.KD_REGULRAZIATION
+        loss_dict = self.model(data)
+        loss = {}
+        if self.iter > self.burn_in:
+            loss.update(self.model(data, clipcap_model=self.clipcap_model, branch="caption_consistency", KD_regularization=kd))
+            loss["cont_region_loss"] = self.model(data, clipcap_model=self.clipcap_model,
+                                                  branch="caption_consistency_regionLevel", KD_regularization=kd)
+        else:
+            cc = self.model(data, clipcap_model=self.clipcap_model, branch="caption_consistency", KD_regularization=False)
+            for k in cc:
+                loss[k] = cc[k] * 0.0
+        loss_dict.update(loss)
+        return loss_dict
+
+    def run_step(self):
+        assert self.model.training, "[SimpleTrainer] model was changed to eval mode!"
+        start = time.perf_counter()
+        data = next(self._data_loader_iter)
+        data_time = time.perf_counter() - start
+        self.buckets.zero()                       # model.zero_grad() / optimizer.zero_grad()
+        loss_dict = self.compute_losses(data)
+        losses = sum(loss_dict.values())
+        losses.backward()
+        self.buckets.all_reduce_mean()
+        self.optimizer.iteration = self.iter
+        self.optimizer.step()
+        if self.metrics_period and self.iter % self.metrics_period == 0:
+            self._write_metrics(loss_dict, data_time)
+        self.iter += 1
+        return loss_dict
+
+    def _write_metrics(self, loss_dict, data_time):
+        """train_loop.py:391-431: one device sync, NaN/Inf check; cross-rank mean via one small all-reduce."""
+        keys = sorted(loss_dict.keys())
+        vec = torch.stack([loss_dict[k].detach().float() for k in keys])
+        if get_world_size() > 1:
+            dist.all_reduce(vec)
+            vec = vec / get_world_size()
+        vals = vec.cpu().tolist()
+        metrics = dict(zip(keys, vals))
+        total = sum(vals)
+        if not all(map(lambda v: v == v and abs(v) != float("inf"), [total])):
+            raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.iter}!\nloss_dict = {metrics}")
+        self.storage.update(metrics)
+        self.storage["total_loss"] = total
+        self.storage["data_time"] = data_time
+
+
+class SyntheticPairedLoader:
+    """Infinite loader of seeded VOC-shaped paired samples (stand-in for build_detection_train_loader; the real
+    VOC+Clipart loader is a 'next' row).  Per-rank batch = IMS_PER_BATCH // world (data/build.py:287)."""
+
+    def __init__(self, per_rank_batch, height=800, width=1333, rank=0, device="cuda", num_classes=20, pool=2):
+        from . import synthetic
+        from .structures import Boxes, Instances
+        self.batches = []
+        for it in range(pool):
+            b = synthetic.make_batch(per_rank_batch, height, width, rank, it, num_classes=num_classes)
+            for x in b:
+                x["image"], x["image_trgt"] = x["image"].to(device), x["image_trgt"].to(device)
+                i = x["instances"]
+                x["instances"] = Instances((height, width), gt_boxes=Boxes(i["gt_boxes"].to(device)), gt_classes=i["gt_classes"].to(device))
+            self.batches.append(b)
+        self.i = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        return b
+
+
+def build_trainer(cfg, per_rank_batch, height=800, width=1333, seed=1):
+    from .modeling import build_model
+    rank, _ = get_rank(), get_world_size()
+    model = build_model(cfg)
+    model.proposal_generator.sample_generator.manual_seed(seed + rank)
+    model.roi_heads.sample_generator.manual_seed(seed + rank + 7919)
+    model.region_generator.manual_seed(seed + rank + 104729)
+    opt = build_optimizer(cfg, model)
+    loader = SyntheticPairedLoader(per_rank_batch, height, width, rank, cfg.MODEL.DEVICE, cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+    return SimpleTrainer(model, loader, opt, cfg)

@@ -29,6 +29,7 @@ def _L():
         L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_attn_tokens_fwd.argtypes = [vp] * 3 + [ci] * 4 + [vp]
         L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 2 + [ci] * 4 + [vp]
+        L.cddmsl_relu_bwd.argtypes = [vp, vp, vp, c_long, ci, ci, vp]
         L.cddmsl_colsum.argtypes = [vp, vp, c_long, ci, ci, ci, vp]
         L.cddmsl_sgd_clip_step.argtypes = [vp] * 4 + [ci, vp] + [cf] * 4 + [ci, vp]
         L.cddmsl_roi_align_forward.argtypes = [vp] * 4 + [ci] * 7 + [cf, ci, ci, ci, vp]
@@ -193,6 +194,17 @@ def attn_tokens_bwd(dtok):
     return dx
 
 
+def relu_bwd(g, y):
+    """dx = g * (y > 0) in y's dtype; g may be f32 while y is bf16."""
+    require_cuda(g, y)
+    assert g.is_contiguous() and y.is_contiguous() and g.numel() == y.numel()
+    g_f32 = int(g.dtype == torch.float32 and y.dtype != torch.float32)
+    assert g_f32 or g.dtype == y.dtype
+    dx = torch.empty_like(y)
+    check(_L().cddmsl_relu_bwd(ptr(g), ptr(y), ptr(dx), y.numel(), g_f32, _dt(y), stream_ptr()), "cddmsl_relu_bwd")
+    return dx
+
+
 def colsum(x2d, period=1, out=None):
     """f32 column sums of x [rows, cols] (rows folded modulo `period`)."""
     require_cuda(x2d, out)
@@ -204,6 +216,11 @@ def colsum(x2d, period=1, out=None):
     return out
 
 
+def same_layout(a, b):
+    """Same shape and the same element order in memory (strides of size-1 dims are irrelevant)."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 def sgd_clip_step(params, grads, moms, norm_ws, lr, momentum, wd, clip, first_step):
     """Fused per-parameter grad-norm clip + SGD(momentum, wd) over a list of f32 tensors (solver/build.py:59-130)."""
     n = len(params)
@@ -212,7 +229,7 @@ def sgd_clip_step(params, grads, moms, norm_ws, lr, momentum, wd, clip, first_st
     require_cuda(*params, *grads, *moms)
     for p, g, m in zip(params, grads, moms):
         assert p.dtype == g.dtype == m.dtype == torch.float32
-        assert p.stride() == g.stride() == m.stride(), "param/grad/momentum must share a memory layout"
+        assert same_layout(p, g) and same_layout(p, m), "param/grad/momentum must share a memory layout"
     P = (c_void_p * n)(*[p.data_ptr() for p in params])
     G = (c_void_p * n)(*[g.data_ptr() for g in grads])
     M = (c_void_p * n)(*[m.data_ptr() for m in moms])

@@ -1,0 +1,407 @@
+"""Host-side layers: ``torch.autograd.Function`` wrappers whose forward/backward are sequences of C-ABI
+HIP kernels (cddmsl_amd.hip).  This mirrors the reference's own native-op convention
+(``autograd.Function`` over ``_C.<op>_forward/_backward``, detectron2/layers/roi_align_rotated.py:11-47).
+
+Conventions
+  * activations are NHWC in the compute dtype T (bf16 throughput path / f32 parity path);
+  * parameters are f32 masters with the reference's names; conv weights are ``channels_last`` OIHW
+    (= [Cout][KH][KW][Cin] in memory), so the kernels read them in place;
+  * weight gradients are accumulated by the wgrad kernels straight into ``param.grad`` (f32, same
+    memory layout as the parameter) -- the Functions return ``None`` for parameter inputs.
+"""
+import torch
+
+from . import hip
+
+_STEP = [0]  # bumped by the optimizer; keys the per-step cache of prepared (cast/transposed) weights
+
+
+def bump_weight_version():
+    _STEP[0] += 1
+
+
+def _grad_buf(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+    return p.grad
+
+
+def _ohwi(w):
+    """[Cout,Cin,KH,KW] channels_last parameter (or a 2-D linear weight) -> contiguous [Cout,KH,KW,Cin] view."""
+    if w.dim() == 2:
+        return w.view(w.shape[0], 1, 1, w.shape[1])
+    v = w.permute(0, 2, 3, 1)
+    assert v.is_contiguous(), "conv weights must be channels_last"
+    return v
+
+
+class PreparedWeight:
+    """Per-step cache of the T-dtype forward weights and the flipped/transposed (and BN-scaled) dgrad weights."""
+
+    def __init__(self, param, scale=None, frozen=False):
+        self.param, self.scale, self.frozen = param, scale, frozen
+        self._key = None
+        self._wf = self._wd = None
+
+    def get(self, dtype, need_dgrad=True):
+        key = (dtype, -1 if self.frozen else _STEP[0], self.param.data_ptr())
+        if key != self._key or (need_dgrad and self._wd is None):
+            wf, wd = hip.weight_prep(_ohwi(self.param.detach()), self.scale, dtype, True, need_dgrad)
+            self._wf, self._wd, self._key = wf, (wd if need_dgrad else None), key
+        return self._wf, self._wd
+
+
+def cat_prepared(weights, dtype):
+    """Concatenate several [Ni,K] / 1x1 weights into one [sum Ni,1,1,K] GEMM operand (fused heads)."""
+    return torch.cat([hip.weight_prep(_ohwi(w.detach()), None, dtype, True, False)[0] for w in weights], dim=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# generic conv / linear with bias (+ReLU)   -- RPN head, projections, projector, mapper linears
+# ------------------------------------------------------------------------------------------------
+class ConvFn(torch.autograd.Function):
+    """y = relu?(conv(x, W) + b).  x NHWC T; W f32 master; optional f32 output.  ``train_w`` False = frozen
+    weights (input gradient only)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, pw, bias, stride, pad, relu, out_f32, train_w):
+        wf, _ = pw.get(x.dtype, need_dgrad=False)
+        y = hip.conv_fwd(x, wf, None, None if bias is None else bias.detach(), relu=relu, stride=stride, pad=pad, out_f32=out_f32)
+        ctx.pw, ctx.bias, ctx.cfg = pw, bias, (stride, pad, relu, out_f32, train_w)
+        ctx.save_for_backward(x, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        stride, pad, relu, out_f32, train_w = ctx.cfg
+        T = x.dtype
+        dy = dy.contiguous()
+        if relu:
+            dy = hip.relu_bwd(dy, y if y.dtype == T else y.to(T))
+        elif dy.dtype != T:
+            dy = dy.to(T)
+        w = ctx.pw.param
+        if train_w:
+            hip.conv_wgrad(x, dy, _ohwi(w).shape, None, stride=stride, pad=pad, out=_ohwi(_grad_buf(w)))
+            if ctx.bias is not None:
+                hip.colsum(dy.view(-1, dy.shape[-1]), out=_grad_buf(ctx.bias))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            assert stride == 1, "input gradient of a strided conv is not on the hot path"
+            _, wd = ctx.pw.get(T, need_dgrad=True)
+            KH = _ohwi(w).shape[1]
+            dx = hip.conv_fwd(dy, wd, stride=1, pad=KH - 1 - pad)
+        return dx, None, None, None, None, None, None, None, None
+
+
+def conv(x, pw, bias=None, stride=1, pad=0, relu=False, out_f32=False, train_w=True):
+    anchor = pw.param if train_w else None
+    return ConvFn.apply(x, anchor, pw, bias, stride, pad, relu, out_f32, train_w)
+
+
+def linear(x2d, pw, bias=None, relu=False, out_f32=False, train_w=True):
+    M, K = x2d.shape
+    y = conv(x2d.contiguous().view(1, 1, M, K), pw, bias, 1, 0, relu, out_f32, train_w)
+    return y.view(M, -1)
+
+
+class FusedHeadsFn(torch.autograd.Function):
+    """Several 1x1 heads over the same input as ONE GEMM (N = sum of head widths, zero-padded to a multiple of 8 so
+    every row of y / dy is whole 16-byte chunks): the RPN's objectness (A) + anchor-delta (4A) heads, rpn.py:173-176."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, heads, out_f32):
+        T = x.dtype
+        K = heads[0][0].shape[1] if heads[0][0].dim() == 2 else heads[0][0].shape[1]
+        ws = [w.detach().reshape(w.shape[0], -1) for w, _ in heads]
+        n = sum(w.shape[0] for w in ws)
+        npad = (n + 7) // 8 * 8
+        wcat = torch.zeros(npad, 1, 1, ws[0].shape[1], device=x.device, dtype=torch.float32)
+        wcat[:n, 0, 0] = torch.cat(ws, dim=0)
+        bcat = torch.zeros(npad, device=x.device, dtype=torch.float32)
+        bcat[:n] = torch.cat([b.detach() for _, b in heads])
+        wf, wd = hip.weight_prep(wcat, None, T, True, True)
+        y = hip.conv_fwd(x, wf, None, bcat, out_f32=out_f32)
+        ctx.heads, ctx.wd, ctx.npad = heads, wd, npad
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        T = x.dtype
+        dy = dy.contiguous()
+        if dy.dtype != T:
+            dy = dy.to(T)
+        K = x.shape[-1]
+        dw = hip.conv_wgrad(x, dy, (ctx.npad, 1, 1, K))
+        db = hip.colsum(dy.view(-1, ctx.npad))
+        off = 0
+        for w, b in ctx.heads:
+            n = w.shape[0]
+            _grad_buf(w).view(n, -1).add_(dw[off:off + n].view(n, -1)) if w.dim() == 2 else \
+                _ohwi(_grad_buf(w)).add_(dw[off:off + n])
+            _grad_buf(b).add_(db[off:off + n])
+            off += n
+        dx = hip.conv_fwd(dy, ctx.wd) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None
+
+
+def fused_heads(x, heads, out_f32=True):
+    """heads: list of (weight [Ni,K,1,1] or [Ni,K], bias [Ni]).  Returns y [..., Npad]; slice per head."""
+    return FusedHeadsFn.apply(x, heads[0][0], heads, out_f32)
+
+
+# ------------------------------------------------------------------------------------------------
+# CLIP residual stage: a chain of Bottlenecks as ONE autograd node (fused FrozenBN/ReLU/avgpool/residual)
+# ------------------------------------------------------------------------------------------------
+class BlockParams:
+    """Weights + folded FrozenBN affine of one Bottleneck (clip_backbone.py:14-70)."""
+
+    def __init__(self, w1, w2, w3, wd, bn1, bn2, bn3, bnd, stride, frozen):
+        self.stride, self.frozen = stride, frozen
+        self.bn = (bn1, bn2, bn3, bnd)  # each = (scale, bias) f32
+        self.w = (w1, w2, w3, wd)
+        self.pw = tuple(None if w is None else PreparedWeight(w, b[0], frozen) for w, b in zip(self.w, self.bn))
+
+
+def _block_forward(x, bp, save):
+    T = x.dtype
+    (s1, b1), (s2, b2), (s3, b3), bnd = bp.bn
+    w1, _ = bp.pw[0].get(T, False)
+    w2, _ = bp.pw[1].get(T, False)
+    w3, _ = bp.pw[2].get(T, False)
+    pool = bp.stride > 1
+    o1 = hip.conv_fwd(x, w1, s1, b1, relu=True)
+    o2 = hip.conv_fwd(o1, w2, s2, b2, relu=True, pad=1)
+    if bp.pw[3] is not None:
+        wd, _ = bp.pw[3].get(T, False)
+        idn = hip.conv_fwd(x, wd, bnd[0], bnd[1], pool=pool)
+    else:
+        idn = x
+    out = hip.conv_fwd(o2, w3, s3, b3, residual=idn, relu=True, pool=pool)
+    return out, ((o1, o2) if save else None)
+
+
+def _block_backward(gs, x, o1, o2, bp, need_dx, mask_x):
+    """gs = dL/d(pre-ReLU sum) of this block (already masked by out>0).  Returns dL/dx, masked by x>0 when
+    ``mask_x`` (x is the previous block's post-ReLU output) so it is directly the previous block's ``gs``."""
+    T = x.dtype
+    (s1, _), (s2, _), (s3, _), bnd = bp.bn
+    pool = bp.stride > 1
+    w1p, w2p, w3p, wdp = bp.w
+    shp = lambda w: _ohwi(w).shape
+    hip.conv_wgrad(o2, gs, shp(w3p), s3, pool=pool, out=_ohwi(_grad_buf(w3p)))
+    _, w3d = bp.pw[2].get(T, True)
+    if pool:
+        dp2 = hip.conv_fwd(gs, w3d)
+        dpre2 = hip.avgpool2_bwd(dp2, tuple(o2.shape), mask=o2)
+    else:
+        dpre2 = hip.conv_fwd(gs, w3d, relu_mask=o2)
+    hip.conv_wgrad(o1, dpre2, shp(w2p), s2, pad=1, out=_ohwi(_grad_buf(w2p)))
+    _, w2d = bp.pw[1].get(T, True)
+    dpre1 = hip.conv_fwd(dpre2, w2d, pad=1, relu_mask=o1)
+    hip.conv_wgrad(x, dpre1, shp(w1p), s1, out=_ohwi(_grad_buf(w1p)))
+    if wdp is not None:
+        hip.conv_wgrad(x, gs, shp(wdp), bnd[0], pool=pool, out=_ohwi(_grad_buf(wdp)))
+    if not need_dx:
+        return None
+    if wdp is not None:
+        _, wdd = bp.pw[3].get(T, True)
+        dxb = hip.conv_fwd(gs, wdd)
+        if pool:
+            dxb = hip.avgpool2_bwd(dxb, tuple(x.shape))
+    else:
+        dxb = gs
+    _, w1d = bp.pw[0].get(T, True)
+    return hip.conv_fwd(dpre1, w1d, residual=dxb, relu_mask=x if mask_x else None)
+
+
+class ResStageFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, blocks):
+        saved = [x]
+        cur = x
+        for bp in blocks:
+            cur, mids = _block_forward(cur, bp, True)
+            saved += [mids[0], mids[1], cur]
+        ctx.blocks = blocks
+        ctx.save_for_backward(*saved)
+        return cur
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        blocks = ctx.blocks
+        need_dx = ctx.needs_input_grad[0]
+        gs = hip.relu_bwd(g.contiguous(), saved[-1])   # mask by the stage output's ReLU
+        for i in range(len(blocks) - 1, -1, -1):
+            x, o1, o2 = saved[3 * i], saved[3 * i + 1], saved[3 * i + 2]
+            gs = _block_backward(gs, x, o1, o2, blocks[i], need_dx or i > 0, mask_x=i > 0)
+        return gs, None, None
+
+
+def res_stage(x, blocks, frozen):
+    """Runs a residual stage.  Frozen stages (FREEZE_AT) and no-grad calls keep no activations."""
+    if frozen or not torch.is_grad_enabled():
+        cur = x
+        for bp in blocks:
+            cur, _ = _block_forward(cur, bp, False)
+        return cur
+    return ResStageFn.apply(x, blocks[0].w[0], blocks)
+
+
+# ------------------------------------------------------------------------------------------------
+# RoIAlign (layers/roi_align.py:7-65, poolers.py:190-229)
+# ------------------------------------------------------------------------------------------------
+class RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, rois, roi_start, out_size, scale, sampling_ratio, aligned):
+        y = hip.roi_align_forward(x, rois, out_size, out_size, scale, sampling_ratio, aligned)
+        ctx.save_for_backward(rois, roi_start)
+        ctx.meta = (tuple(x.shape), scale, sampling_ratio, aligned)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rois, roi_start = ctx.saved_tensors
+        shape, scale, sr, aligned = ctx.meta
+        dx = hip.roi_align_backward(dy.contiguous(), rois, roi_start, shape, scale, sr, aligned)
+        return dx, None, None, None, None, None, None
+
+
+def roi_align(x, rois, roi_start, out_size, scale, sampling_ratio, aligned=True):
+    assert rois.dim() == 2 and rois.size(1) == 5  # layers/roi_align.py:55
+    return RoIAlignFn.apply(x, rois, roi_start, out_size, scale, sampling_ratio, aligned)
+
+
+# ------------------------------------------------------------------------------------------------
+# AttentionPool2d (clip_backbone.py:73-107), query-0-only
+# ------------------------------------------------------------------------------------------------
+class AttnPoolParams:
+    def __init__(self, pos, q_w, q_b, k_w, k_b, v_w, v_b, c_w, c_b, heads, frozen=False):
+        self.pos, self.heads, self.frozen = pos, heads, frozen
+        self.q_w, self.q_b, self.k_w, self.k_b, self.v_w, self.v_b, self.c_w, self.c_b = q_w, q_b, k_w, k_b, v_w, v_b, c_w, c_b
+        self.pq = PreparedWeight(q_w, None, frozen)
+        self.pk = PreparedWeight(k_w, None, frozen)
+        self.pv = PreparedWeight(v_w, None, frozen)
+        self.pc = PreparedWeight(c_w, None, frozen)
+
+
+class AttnPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, ap):
+        """x [K,h,w,C] NHWC T with h*w+1 == len(pos)  ->  [K, out_dim] f32"""
+        T = x.dtype
+        K, h, w, C = x.shape
+        P = h * w
+        assert ap.pos.shape[0] == P + 1, "attention pool needs a 7x7 map (clip_backbone.py:86)"
+        tok = hip.attn_tokens_fwd(x.view(K, P, C), ap.pos.detach())
+        wk, _ = ap.pk.get(T, False)
+        wv, _ = ap.pv.get(T, False)
+        wq, _ = ap.pq.get(T, False)
+        wc, _ = ap.pc.get(T, False)
+        wkv = torch.cat([wk, wv], dim=0)
+        bkv = torch.cat([ap.k_b.detach(), ap.v_b.detach()])
+        kv = hip.conv_fwd(tok.view(1, 1, K * (P + 1), C), wkv, None, bkv).view(K, P + 1, 2 * C)
+        # token-0 rows only: a 1x1 "conv" over [K,1,P+1,C] with stride P+1 picks row 0 of every region
+        q0 = hip.conv_fwd(tok.view(K, 1, P + 1, C), wq, None, ap.q_b.detach(), stride=P + 1).view(K, C)
+        o, p = hip.attnpool_core_fwd(q0, kv, ap.heads)
+        out = hip.conv_fwd(o.view(1, 1, K, C), wc, None, ap.c_b.detach(), out_f32=True).view(K, -1)
+        ctx.ap = ap
+        ctx.save_for_backward(tok, kv, q0, o, p)
+        ctx.shape = (K, h, w, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ap = ctx.ap
+        tok, kv, q0, o, p = ctx.saved_tensors
+        K, h, w, C = ctx.shape
+        P = h * w
+        T = tok.dtype
+        dout_t = dout.contiguous().to(T)
+        train = not ap.frozen
+        if train:
+            hip.conv_wgrad(o.view(1, 1, K, C), dout_t.view(1, 1, K, -1), _ohwi(ap.c_w).shape, out=_ohwi(_grad_buf(ap.c_w)))
+            hip.colsum(dout_t, out=_grad_buf(ap.c_b))
+        _, wcd = ap.pc.get(T, True)
+        do = hip.conv_fwd(dout_t.view(1, 1, K, -1), wcd).view(K, C)
+        dq0, dkv = hip.attnpool_core_bwd(do, q0, kv, p, ap.heads)
+        tok4 = tok.view(1, 1, K * (P + 1), C)
+        dkv4 = dkv.view(1, 1, K * (P + 1), 2 * C)
+        if train:
+            dk = dkv[:, :, :C].contiguous().view(1, 1, -1, C)
+            dv = dkv[:, :, C:].contiguous().view(1, 1, -1, C)
+            hip.conv_wgrad(tok4, dk, _ohwi(ap.k_w).shape, out=_ohwi(_grad_buf(ap.k_w)))
+            hip.conv_wgrad(tok4, dv, _ohwi(ap.v_w).shape, out=_ohwi(_grad_buf(ap.v_w)))
+            gb = hip.colsum(dkv.view(-1, 2 * C))
+            _grad_buf(ap.k_b).add_(gb[:C])
+            _grad_buf(ap.v_b).add_(gb[C:])
+            hip.conv_wgrad(tok.view(K, 1, P + 1, C), dq0.view(K, 1, 1, C), _ohwi(ap.q_w).shape, stride=P + 1,
+                           out=_ohwi(_grad_buf(ap.q_w)))
+            hip.colsum(dq0, out=_grad_buf(ap.q_b))
+        _, wkd = ap.pk.get(T, True)
+        _, wvd = ap.pv.get(T, True)
+        wkvd = torch.cat([wkd, wvd], dim=3)                       # [C,1,1,2C]: dtok = dk Wk + dv Wv
+        dtok = hip.conv_fwd(dkv4, wkvd).view(K, P + 1, C)
+        _, wqd = ap.pq.get(T, True)
+        dtok[:, 0, :] += hip.conv_fwd(dq0.view(1, 1, K, C), wqd).view(K, C)
+        if train:
+            hip.colsum(dtok.view(-1, C), period=P + 1, out=_grad_buf(ap.pos))
+        dx = hip.attn_tokens_bwd(dtok).view(K, h, w, C) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
+def attnpool(x, ap):
+    return AttnPoolFn.apply(x, None if ap.frozen else ap.q_w, ap)
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32 heads: cosine-logit classifier (fast_rcnn.py:546-572) and contrastive loss (rcnn.py:308-317)
+# ------------------------------------------------------------------------------------------------
+class CosineLogitsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wn, temperature):
+        scores, inv = hip.cosine_logits_fwd(x.contiguous(), wn, temperature)
+        ctx.save_for_backward(x, wn, inv)
+        ctx.t = temperature
+        return scores
+
+    @staticmethod
+    def backward(ctx, ds):
+        x, wn, inv = ctx.saved_tensors
+        return hip.cosine_logits_bwd(ds, x.contiguous(), wn, inv, ctx.t), None, None
+
+
+def cosine_logits(x, wn, temperature):
+    return CosineLogitsFn.apply(x, wn, temperature)
+
+
+class ContrastiveFn(torch.autograd.Function):
+    """0.5*(CE(S, arange) + CE(S^T, arange)), S = norm(a) norm(b)^T; a, b f32 [n, d]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        an, ia = hip.l2norm_fwd(a.contiguous(), 0.0)
+        bn, ib = hip.l2norm_fwd(b.contiguous(), 0.0)
+        S = hip.linear_fwd(an, bn)                       # exact-f32 MFMA contraction
+        loss, rl, cl = hip.contrastive_fwd(S)
+        ctx.save_for_backward(an, ia, bn, ib, S, rl, cl)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        an, ia, bn, ib, S, rl, cl = ctx.saved_tensors
+        dS = hip.contrastive_bwd(S, rl, cl, g)
+        n = dS.shape[0]
+        pad = (-n) % 4                                   # GEMM rows are whole 16-byte chunks: zero-pad the contraction
+        P = (lambda t: torch.nn.functional.pad(t, (0, pad))) if pad else (lambda t: t)
+        dan = hip.linear_fwd(P(dS).contiguous(), P(bn.t()).contiguous())
+        dbn = hip.linear_fwd(P(dS.t()).contiguous(), P(an.t()).contiguous())
+        return hip.l2norm_bwd(dan, an, ia), hip.l2norm_bwd(dbn, bn, ib)
+
+
+def contrastive_loss(a, b):
+    return ContrastiveFn.apply(a, b)

@@ -1,0 +1,97 @@
+"""ClipCap vision-to-language mapper (frozen) -- detectron2/modeling/backbone/clipcap/clipcap.py:39-163,714-719.
+
+Only ``TransformerMapper`` is built (``ClipCaptionModel.clip_project``, engine/train_loop.py:281-288); GPT-2 is
+never constructed (it is off the hot path and needs a network fetch).  Parameter names match ``clip_project.*``.
+The linears (31 M + 38 M frozen parameters, 3.13 GMAC/sample) run on the HIP MFMA GEMM with input-gradient only;
+LayerNorm / the 80-token softmax are small fp32 elementwise pieces kept on torch ops this round ("next").
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import layers
+
+
+class _Lin(nn.Module):
+    def __init__(self, i, o, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i))
+        self.bias = nn.Parameter(torch.empty(o)) if bias else None
+        self._pw = None
+
+    def forward(self, x2d, relu=False):
+        if self._pw is None or self._pw.param is not self.weight:
+            self._pw = layers.PreparedWeight(self.weight, None, frozen=True)
+        return layers.linear(x2d, self._pw, self.bias, relu=relu, out_f32=True, train_w=False)
+
+
+class MlpTransformer(nn.Module):
+    def __init__(self, in_dim, h_dim):
+        super().__init__()
+        self.fc1, self.fc2 = _Lin(in_dim, h_dim), _Lin(h_dim, in_dim)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, dim, num_heads, bias=False):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.to_queries = _Lin(dim, dim, bias)
+        self.to_keys_values = _Lin(dim, dim * 2, bias)
+        self.project = _Lin(dim, dim)
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=2.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = MultiHeadAttention(dim, num_heads, bias=False)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MlpTransformer(dim, int(dim * mlp_ratio))
+
+
+class Transformer(nn.Module):
+    def __init__(self, dim, num_heads, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([TransformerLayer(dim, num_heads) for _ in range(num_layers)])
+
+
+class TransformerMapper(nn.Module):
+    def __init__(self, dim_clip=1024, dim_embedding=768, prefix_length=40, clip_length=40, num_layers=8,
+                 compute_dtype=torch.bfloat16):
+        super().__init__()
+        self.clip_length, self.dim, self.compute_dtype = clip_length, dim_embedding, compute_dtype
+        self.transformer = Transformer(dim_embedding, 8, num_layers)
+        self.linear = _Lin(dim_clip, clip_length * dim_embedding)
+        self.prefix_const = nn.Parameter(torch.randn(prefix_length, dim_embedding))
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        """x [N, dim_clip] f32 -> [N, prefix_length, dim] f32   (clipcap.py:151-155)"""
+        T, d = self.compute_dtype, self.dim
+        n = x.shape[0]
+        h = self.linear(x.to(T)).view(n, self.clip_length, d)
+        h = torch.cat((h, self.prefix_const.unsqueeze(0).expand(n, -1, -1)), dim=1)       # [n, 80, d] f32
+        t = h.shape[1]
+        for lyr in self.transformer.layers:
+            a = lyr.attn
+            H = a.num_heads
+            y = F.layer_norm(h, (d,), lyr.norm1.weight, lyr.norm1.bias).to(T).view(n * t, d)
+            q = a.to_queries(y).view(n, t, H, d // H).permute(0, 2, 1, 3)
+            kv = a.to_keys_values(y).view(n, t, 2, H, d // H)
+            k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
+            att = torch.softmax((q @ k.transpose(-1, -2)) * a.scale, dim=-1)
+            o = (att @ v).permute(0, 2, 1, 3).reshape(n * t, d)
+            h = h + a.project(o.to(T)).view(n, t, d)
+            y = F.layer_norm(h, (d,), lyr.norm2.weight, lyr.norm2.bias).to(T).view(n * t, d)
+            y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True).to(T))
+            h = h + y.view(n, t, d)
+        return h[:, self.clip_length:]
+
+
+def v2l(prefix, model):
+    """clipcap.py:714-719: the LAST of the 40 mapped tokens."""
+    prefix_length, size = 40, 768
+    embed = model(prefix).reshape(-1, prefix_length, size)[:, -1, :]
+    return embed.reshape(embed.shape[0], -1)

@@ -1,0 +1,171 @@
+"""``GeneralizedRCNN`` (CDDMSL variant) on the HIP hot path -- detectron2/modeling/meta_arch/rcnn.py:37-623,758-768,
+meta_arch/build.py:16-25, backbone/clipcap/gather.py:5-20.
+
+Same call contract as the reference: ``model(batched_inputs, clipcap_model=None, branch='supervised',
+KD_regularization=True)`` returning the loss dict (supervised: loss_cls, loss_box_reg, loss_rpn_cls, loss_rpn_loc;
+'caption_consistency': cont_loss[, kd_loss]; 'caption_consistency_regionLevel': a bare tensor).
+Intended semantics are kept where the reference as shipped cannot run (SURVEY.md warnings): world_size 1 needs no
+process group; the unused full-image layer4 of the supervised / region-level branches is not computed.
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .. import hip, layers
+from ..registry import META_ARCH_REGISTRY
+from ..structures import ImageList, as_instances
+from .backbone import build_backbone, to_nchw
+from .clipcap import v2l
+from .roi_heads import build_roi_heads
+from .rpn import build_proposal_generator
+
+
+class GatherLayer(torch.autograd.Function):
+    """gather.py:5-20: all_gather forward; backward keeps this rank's slice only (no reduction)."""
+
+    @staticmethod
+    def forward(ctx, input):
+        ctx.save_for_backward(input)
+        output = [torch.zeros_like(input) for _ in range(dist.get_world_size())]
+        dist.all_gather(output, input.contiguous())
+        return tuple(output)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (input,) = ctx.saved_tensors
+        grad_out = torch.zeros_like(input)
+        grad_out[:] = grads[dist.get_rank()]
+        return grad_out
+
+
+def gather_cat(x):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return torch.cat(GatherLayer.apply(x), dim=0)
+    return x
+
+
+class _Linear(nn.Linear):
+    def pw(self):
+        if getattr(self, "_pw", None) is None or self._pw.param is not self.weight:
+            self._pw = layers.PreparedWeight(self.weight, None, frozen=False)
+        return self._pw
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = build_backbone(cfg)
+        self.offline_backbone = build_backbone(cfg)
+        for p in self.offline_backbone.parameters():
+            p.requires_grad = False
+        for st in (self.offline_backbone.layer1, self.offline_backbone.layer2, self.offline_backbone.layer3, self.offline_backbone.layer4):
+            for blk in st:
+                blk.frozen = True
+        self.offline_backbone.eval()
+        self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
+        self.roi_heads = build_roi_heads(cfg, self.backbone.output_shape())
+        self.input_format = cfg.INPUT.FORMAT
+        self.pixel_mean_list, self.pixel_std_list = list(cfg.MODEL.PIXEL_MEAN), list(cfg.MODEL.PIXEL_STD)
+        self.register_buffer("pixel_mean", torch.tensor(self.pixel_mean_list).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(self.pixel_std_list).view(-1, 1, 1), False)
+        assert sum(self.pixel_mean_list) < 3.0 and self.input_format == "RGB", "CLIP models take RGB/255 inputs (rcnn.py:87-91)"
+        self.div_pixel = True
+        self.use_clip_c4 = cfg.MODEL.BACKBONE.NAME == "build_clip_resnet_backbone"
+        self.use_clip_attpool = cfg.MODEL.ROI_HEADS.NAME == "CLIPRes5ROIHeads" and cfg.MODEL.CLIP.USE_TEXT_EMB_CLASSIFIER
+        self.projector = nn.Sequential(_Linear(768, 768), nn.ReLU(), _Linear(768, 256))   # rcnn.py:95-99
+        self.compute_dtype = self.backbone.compute_dtype
+        self.regions_per_image = 16                                                        # rcnn.py:437
+        self.region_generator = torch.Generator()
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ------------------------------------------------------------------ preprocessing (fused normalise + pad, NHWC)
+    def _images(self, batched_inputs, key):
+        return [x[key].to(self.device).contiguous() for x in batched_inputs]
+
+    def preprocess_image(self, batched_inputs, key="image"):
+        """rcnn.py:758-768 / :196-207 -> (NHWC padded tensor in the compute dtype, image_sizes)"""
+        imgs = self._images(batched_inputs, key)
+        sizes = [tuple(i.shape[-2:]) for i in imgs]
+        Hp, Wp = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        return hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype), sizes
+
+    def preprocess_image_train(self, batched_inputs):
+        """rcnn.py:161-179 -> two NHWC [N,224,224,Cp] tensors (source, target)"""
+        outs = []
+        for key in ("image", "image_trgt"):
+            imgs = self._images(batched_inputs, key)
+            Hp, Wp = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
+            outs.append(hip.preprocess224(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype))
+        return outs
+
+    # ------------------------------------------------------------------ pieces
+    def project(self, x):
+        """projector MLP 768 -> 768 -> ReLU -> 256 (f32 in/out, GEMMs in the compute dtype)"""
+        T = self.compute_dtype
+        l0, l2 = self.projector[0], self.projector[2]
+        h = layers.linear(x.to(T), l0.pw(), l0.bias, relu=True, out_f32=True)
+        return layers.linear(h.to(T), l2.pw(), l2.bias, out_f32=True)
+
+    def _encode(self, bb, img_nhwc):
+        feats = bb.forward_nhwc(img_nhwc)
+        return bb.attnpool(to_nchw(feats["res5"]))
+
+    def v2l_contrastive(self, images_src, images_target, clipcap_model, KD_regularization=True):
+        """rcnn.py:255-319"""
+        ft = self.project(v2l(self._encode(self.backbone, images_target), clipcap_model))
+        fs = v2l(self._encode(self.backbone, images_src), clipcap_model)
+        kd_loss = None
+        if KD_regularization:
+            with torch.no_grad():
+                teacher = v2l(self._encode(self.offline_backbone, images_src), clipcap_model)
+            kd_loss = torch.nn.functional.l1_loss(teacher.detach(), fs)
+        fs = self.project(fs)
+        ft, fs = gather_cat(ft), gather_cat(fs)
+        return layers.contrastive_loss(ft, fs), kd_loss
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batched_inputs: List[Dict], clipcap_model=None, branch="supervised", KD_regularization=True):
+        assert self.training, "inference is a 'next' row (SURVEY.md 8(f))"
+        if branch == "caption_consistency":                     # rcnn.py:413-421
+            src, tgt = self.preprocess_image_train(batched_inputs)
+            cont, kd = self.v2l_contrastive(src, tgt, clipcap_model, KD_regularization)
+            return {"cont_loss": cont, "kd_loss": kd} if kd is not None else {"cont_loss": cont}
+        if branch == "caption_consistency_regionLevel":         # rcnn.py:422-470
+            src, sizes = self.preprocess_image(batched_inputs, "image")
+            tgt, _ = self.preprocess_image(batched_inputs, "image_trgt")
+            fs = self.backbone.forward_nhwc(src, want_res5=False)["res4"]
+            ft = self.backbone.forward_nhwc(tgt, want_res5=False)["res4"]
+            gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]
+            with torch.no_grad():
+                props, _ = self.proposal_generator.forward_nhwc(sizes, fs.detach(), gts)
+                sel = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image].to(self.device) for p in props]
+                props = [p[s] for p, s in zip(props, sel)]
+            rs, rt = self.roi_heads.forward_get_features({"res4": to_nchw(fs)}, {"res4": to_nchw(ft)}, props, targets=gts,
+                                                         res5=self.backbone.layer4, attnpool=self.backbone.attnpool)
+            es = self.project(v2l(rs, clipcap_model))
+            et = self.project(v2l(rt, clipcap_model))
+            return layers.contrastive_loss(gather_cat(es), gather_cat(et))
+        # supervised: rcnn.py:592-623
+        images, sizes = self.preprocess_image(batched_inputs, "image")
+        gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]
+        res4 = self.backbone.forward_nhwc(images, want_res5=False)["res4"]
+        proposals, proposal_losses = self.proposal_generator.forward_nhwc(sizes, res4, gts)
+        _, detector_losses = self.roi_heads(ImageList(None, sizes), {"res4": to_nchw(res4)}, proposals, gts,
+                                            res5=self.backbone.layer4, attnpool=self.backbone.attnpool)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses
+
+
+def build_model(cfg):
+    """meta_arch/build.py:16-25"""
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model

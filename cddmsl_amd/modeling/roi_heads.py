@@ -1,0 +1,214 @@
+"""ROI heads on the HIP kernels -- detectron2/modeling/roi_heads/{roi_heads.py:123-319, clip_roi_heads.py:28-199,
+fast_rcnn.py:100-127,368-689}, modeling/poolers.py:61-95,190-229.
+
+``CLIPRes5ROIHeads`` borrows the backbone's ``layer4`` and ``attnpool`` at call time exactly like the reference
+(rcnn.py:608-609): RoIAlign 14x14 (HIP) -> layer4 on the K regions as K 14x14 images (MFMA implicit GEMM) ->
+query-0 attention pool (HIP) -> cosine-logit text-embedding classifier (HIP, fp32) + bbox_pred.
+"""
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import hip, layers
+from ..registry import ROI_HEADS_REGISTRY
+from ..structures import Boxes, Instances, ShapeSpec, as_instances
+from .backbone import to_nhwc, to_nchw
+from .rpn import get_deltas, subsample_labels
+
+GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))  # proposal_utils.py:183
+
+
+class ROIPooler(nn.Module):
+    """poolers.py:98-250, single level, ROIAlignV2 (aligned=True)."""
+
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type="ROIAlignV2"):
+        super().__init__()
+        assert len(scales) == 1 and pooler_type == "ROIAlignV2"
+        self.output_size, self.scale, self.sampling_ratio = output_size, scales[0], sampling_ratio
+
+    def forward_nhwc(self, feat, box_lists: List[Boxes]):
+        dev = feat.device
+        counts = [len(b) for b in box_lists]
+        # convert_boxes_to_pooler_format poolers.py:68-95: rois grouped by image, (batch_idx, x0, y0, x1, y1)
+        rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i), device=dev), b.tensor.float()], dim=1)
+                          for i, b in enumerate(box_lists)], dim=0).contiguous()
+        start = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+        return layers.roi_align(feat, rois, start, self.output_size, self.scale, self.sampling_ratio, True)
+
+    def forward(self, x, box_lists):
+        return to_nchw(self.forward_nhwc(to_nhwc(x[0]), box_lists))
+
+
+class _Linear(nn.Module):
+    def __init__(self, i, o, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i))
+        self.bias = nn.Parameter(torch.zeros(o)) if bias else None
+        self._pw = None
+
+    def pw(self):
+        if self._pw is None or self._pw.param is not self.weight:
+            self._pw = layers.PreparedWeight(self.weight, None, frozen=not self.weight.requires_grad)
+        return self._pw
+
+
+class FastRCNNOutputLayers(nn.Module):
+    """fast_rcnn.py:368-689, RegionCLIP text-embedding classifier branch."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        c = cfg.MODEL.CLIP
+        assert c.USE_TEXT_EMB_CLASSIFIER, "only the CLIP text-embedding classifier is on the hot path"
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        d = c.TEXT_EMB_DIM
+        self.temperature = c.CLSS_TEMP
+        self.cls_score = _Linear(d, self.num_classes, bias=False)
+        self.cls_bg_score = _Linear(d, 1, bias=False)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.constant_(self.cls_bg_score.weight, 0)
+        if c.TEXT_EMB_PATH:
+            self.cls_score.weight.data.copy_(torch.load(c.TEXT_EMB_PATH, map_location="cpu", weights_only=True))
+        self.cls_score.weight.requires_grad = False       # frozen embeddings fast_rcnn.py:453
+        self.cls_bg_score.weight.requires_grad = False    # zero background embedding :458-463
+        self.bbox_pred = _Linear(d, self.num_classes * 4)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        self.box_weights = tuple(cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS)
+        assert cfg.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA == 0.0 and not cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG
+        self.bg_cls_loss_weight = c.BG_CLS_LOSS_WEIGHT
+        self.focal_scaled_loss = c.FOCAL_SCALED_LOSS
+        self.loss_weight = {"loss_box_reg": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT}
+        self.compute_dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[cfg.MODEL.get("COMPUTE_DTYPE", "bf16")]
+        self._wn = None
+        self.storage = {}
+
+    def _text_emb(self):
+        w = self.cls_score.weight
+        if self._wn is None or self._wn[0] != (w.device, w._version):
+            assert float(self.cls_bg_score.weight.abs().max()) == 0.0, "background embedding must stay zero (fast_rcnn.py:460)"
+            self._wn = ((w.device, w._version), F.normalize(w.detach().float(), p=2.0, dim=1).contiguous())
+        return self._wn[1]
+
+    def forward(self, x):
+        """x [R, 1024] f32 -> (scores [R, K+1] f32, deltas [R, 4K] f32)   fast_rcnn.py:529-572"""
+        scores = layers.cosine_logits(x, self._text_emb(), self.temperature)
+        deltas = layers.linear(x.to(self.compute_dtype), self.bbox_pred.pw(), self.bbox_pred.bias, out_f32=True)
+        return scores, deltas
+
+    def losses(self, predictions, proposals):
+        """fast_rcnn.py:574-689"""
+        scores, deltas = predictions
+        gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0)
+        pboxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        gboxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
+        self._log_stats(scores.detach(), gt_classes)
+        ce = F.cross_entropy(scores, gt_classes, reduction="none")
+        if self.focal_scaled_loss is not None:   # focal_loss :624-644
+            p = F.softmax(scores, dim=-1)
+            pt = p[torch.arange(p.size(0), device=p.device), gt_classes]
+            ce = ce * ((1 - pt) ** self.focal_scaled_loss)
+        if self.bg_cls_loss_weight is not None:
+            w = torch.ones_like(ce)
+            w[gt_classes == self.num_classes] = self.bg_cls_loss_weight
+            ce = ce * w
+        loss_cls = ce.mean()
+        fg = torch.nonzero((gt_classes >= 0) & (gt_classes < self.num_classes), as_tuple=True)[0]
+        fg_pred = deltas.view(-1, self.num_classes, 4)[fg, gt_classes[fg]]
+        gt_d = get_deltas(pboxes[fg], gboxes[fg], self.box_weights)
+        loss_box = torch.abs(fg_pred - gt_d).sum() / max(gt_classes.numel(), 1.0)
+        out = {"loss_cls": loss_cls, "loss_box_reg": loss_box}
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
+
+    def _log_stats(self, scores, gt_classes):
+        """_log_classification_stats fast_rcnn.py:100-127 (kept on device; no sync)."""
+        n = gt_classes.numel()
+        if n == 0:
+            return
+        pred = scores.argmax(dim=1)
+        bg = scores.shape[1] - 1
+        fg = (gt_classes >= 0) & (gt_classes < bg)
+        nfg = fg.sum().clamp(min=1)
+        self.storage["fast_rcnn/cls_accuracy"] = (pred == gt_classes).sum() / n
+        self.storage["fast_rcnn/fg_cls_accuracy"] = ((pred == gt_classes) & fg).sum() / nfg
+        self.storage["fast_rcnn/false_negative"] = ((pred == bg) & fg).sum() / nfg
+
+
+@ROI_HEADS_REGISTRY.register()
+class CLIPRes5ROIHeads(nn.Module):
+    def __init__(self, cfg, input_shape: Dict[str, ShapeSpec]):
+        super().__init__()
+        r = cfg.MODEL.ROI_HEADS
+        self.num_classes, self.in_features = r.NUM_CLASSES, r.IN_FEATURES
+        self.batch_size_per_image, self.positive_fraction = r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION
+        self.iou_thresholds, self.iou_labels = list(r.IOU_THRESHOLDS), list(r.IOU_LABELS)
+        self.proposal_append_gt = r.PROPOSAL_APPEND_GT
+        assert len(self.in_features) == 1 and not cfg.MODEL.MASK_ON and not cfg.MODEL.CLIP.ONLY_SAMPLE_FG_PROPOSALS
+        b = cfg.MODEL.ROI_BOX_HEAD
+        self.pooler = ROIPooler(b.POOLER_RESOLUTION, (1.0 / input_shape[self.in_features[0]].stride,),
+                                b.POOLER_SAMPLING_RATIO, b.POOLER_TYPE)
+        out_channels = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS * 8
+        self.box_predictor = FastRCNNOutputLayers(cfg, ShapeSpec(channels=out_channels, height=1, width=1))
+        self.sample_generator = torch.Generator()
+        self.storage = {}
+
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]):
+        """roi_heads.py:236-319 (+ add_ground_truth_to_proposals proposal_utils.py:133-200, _sample_proposals :184-234)"""
+        out, nfg, nbg = [], [], []
+        for prop, tgt in zip(proposals, targets):
+            gtb = tgt.gt_boxes.tensor.float().contiguous()
+            gtc = tgt.gt_classes
+            boxes, logits = prop.proposal_boxes.tensor, prop.objectness_logits
+            if self.proposal_append_gt:
+                boxes = torch.cat([boxes, gtb])
+                logits = torch.cat([logits, GT_LOGIT * torch.ones(len(gtb), device=logits.device)])
+            boxes = boxes.contiguous()
+            midx, mlab = hip.iou_match(gtb, boxes, self.iou_thresholds, self.iou_labels, False)
+            if gtc.numel() > 0:
+                cls = gtc[midx]
+                cls[mlab == 0] = self.num_classes
+                cls[mlab == -1] = -1
+            else:
+                cls = torch.zeros_like(midx) + self.num_classes
+            fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, self.num_classes, self.sample_generator)
+            sidx = torch.cat([fg, bg], dim=0)
+            inst = Instances(prop.image_size)
+            inst.proposal_boxes, inst.objectness_logits, inst.gt_classes = Boxes(boxes[sidx]), logits[sidx], cls[sidx]
+            if gtc.numel() > 0:
+                inst.gt_boxes = Boxes(gtb[midx[sidx]])
+            nfg.append(fg.numel())
+            nbg.append(bg.numel())
+            out.append(inst)
+        self.storage["roi_head/num_fg_samples"] = sum(nfg) / max(len(nfg), 1)
+        self.storage["roi_head/num_bg_samples"] = sum(nbg) / max(len(nbg), 1)
+        return out
+
+    def _shared_roi_transform(self, feat_nhwc, boxes, res5):
+        x = self.pooler.forward_nhwc(feat_nhwc, boxes)
+        return res5.forward_nhwc(x)
+
+    def forward_get_features(self, features_src, features_trgt, proposals, targets=None, res5=None, attnpool=None):
+        """clip_roi_heads.py:117-132: the same boxes pooled from the source and the target map."""
+        if self.training:
+            assert targets
+        boxes = [p.proposal_boxes for p in proposals]
+        fs = self._shared_roi_transform(to_nhwc(features_src[self.in_features[0]]), boxes, res5)
+        ft = self._shared_roi_transform(to_nhwc(features_trgt[self.in_features[0]]), boxes, res5)
+        return attnpool(to_nchw(fs)), attnpool(to_nchw(ft))
+
+    def forward(self, images, features, proposals, targets=None, res5=None, attnpool=None):
+        """clip_roi_heads.py:134-175 (training)."""
+        assert self.training and attnpool is not None, "inference is a 'next' row (SURVEY.md 8(f))"
+        assert targets
+        targets = [as_instances(t) for t in targets]
+        proposals = self.label_and_sample_proposals(proposals, targets)
+        box_features = self._shared_roi_transform(to_nhwc(features[self.in_features[0]]), [p.proposal_boxes for p in proposals], res5)
+        att = attnpool(to_nchw(box_features))
+        predictions = self.box_predictor(att)
+        return [], self.box_predictor.losses(predictions, proposals)
+
+
+def build_roi_heads(cfg, input_shape):
+    return ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, input_shape)

@@ -1,0 +1,234 @@
+"""RPN on the HIP box kernels -- detectron2/modeling/proposal_generator/rpn.py:66-533, proposal_utils.py:22-200,
+anchor_generator.py:81-228, matcher.py, sampling.py, box_regression.py.
+
+Device pipeline per batch (no G x N IoU matrix is ever materialised, no per-image sort/NMS launches):
+  head convs (MFMA implicit GEMM) -> fused IoU+Matcher per image -> host-replayable subsample (CPU generator)
+  -> segmented stable radix sort of all images' logits -> decode+clip top-k -> batched bitmask NMS.
+Random draws follow sampling.py:47-48 order (positives, then negatives, image by image) on one CPU generator so
+the CPU oracle replays them exactly.
+"""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import hip, layers
+from ..registry import ANCHOR_GENERATOR_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY
+from ..structures import Boxes, Instances, as_instances
+from .backbone import to_nhwc, to_nchw
+
+SCALE_CLAMP = math.log(1000.0 / 16)  # box_regression.py:13
+
+
+# ------------------------------------------------------------------------------------------------ box math (fp32 torch glue)
+def get_deltas(src, tgt, weights):
+    """Box2BoxTransform.get_deltas box_regression.py:42-75"""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    tw, th = tgt[:, 2] - tgt[:, 0], tgt[:, 3] - tgt[:, 1]
+    tx, ty = tgt[:, 0] + 0.5 * tw, tgt[:, 1] + 0.5 * th
+    wx, wy, ww, wh = weights
+    return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), dim=1)
+
+
+def subsample_labels(labels, num_samples, positive_fraction, bg_label, gen):
+    """sampling.py:9-54 with both permutations drawn from the replayable CPU generator ``gen``."""
+    positive = torch.nonzero((labels != -1) & (labels != bg_label), as_tuple=True)[0]
+    negative = torch.nonzero(labels == bg_label, as_tuple=True)[0]
+    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
+    num_neg = min(negative.numel(), num_samples - num_pos)
+    perm1 = torch.randperm(positive.numel(), generator=gen)[:num_pos].to(labels.device)
+    perm2 = torch.randperm(negative.numel(), generator=gen)[:num_neg].to(labels.device)
+    return positive[perm1], negative[perm2]
+
+
+# ------------------------------------------------------------------------------------------------ anchors
+@ANCHOR_GENERATOR_REGISTRY.register()
+class DefaultAnchorGenerator(nn.Module):
+    """anchor_generator.py:81-228 (single feature level)."""
+    box_dim = 4
+
+    def __init__(self, cfg=None, input_shape=None, *, sizes=None, aspect_ratios=None, strides=None, offset=0.0):
+        super().__init__()
+        if cfg is not None:
+            sizes, aspect_ratios = cfg.MODEL.ANCHOR_GENERATOR.SIZES, cfg.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS
+            strides, offset = [s.stride for s in input_shape], cfg.MODEL.ANCHOR_GENERATOR.OFFSET
+        assert len(strides) == 1, "C4 models have one feature level"
+        self.strides, self.offset = strides, float(offset)
+        assert 0.0 <= self.offset < 1.0, self.offset
+        cell = []
+        for size in sizes[0]:
+            area = size ** 2.0
+            for r in aspect_ratios[0]:
+                w = math.sqrt(area / r)
+                h = r * w
+                cell.append([-w / 2.0, -h / 2.0, w / 2.0, h / 2.0])
+        self.register_buffer("cell_anchors_0", torch.tensor(cell), persistent=False)
+        self._cache = {}
+
+    @property
+    def num_anchors(self):
+        return [self.cell_anchors_0.shape[0]]
+
+    def grid(self, hf, wf):
+        key = (hf, wf, self.cell_anchors_0.device)
+        if key not in self._cache:
+            self._cache[key] = hip.anchors(self.cell_anchors_0, hf, wf, float(self.strides[0]), self.offset)
+        return self._cache[key]
+
+    def forward(self, features):
+        return [Boxes(self.grid(f.shape[-2], f.shape[-1])) for f in features]
+
+
+def build_anchor_generator(cfg, input_shape):
+    return ANCHOR_GENERATOR_REGISTRY.get(cfg.MODEL.ANCHOR_GENERATOR.NAME)(cfg, input_shape)
+
+
+# ------------------------------------------------------------------------------------------------ head
+class _Conv2d(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k).normal_(std=0.01).contiguous(memory_format=torch.channels_last))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self._pw = None
+
+    def pw(self):
+        if self._pw is None or self._pw.param is not self.weight:
+            self._pw = layers.PreparedWeight(self.weight, None, frozen=False)
+        return self._pw
+
+
+@RPN_HEAD_REGISTRY.register()
+class StandardRPNHead(nn.Module):
+    """rpn.py:66-177: 3x3 conv + ReLU, 1x1 objectness (A), 1x1 anchor deltas (4A)."""
+
+    def __init__(self, cfg=None, input_shape=None, *, in_channels=None, num_anchors=None, box_dim=4):
+        super().__init__()
+        if cfg is not None:
+            in_channels = input_shape[0].channels
+            num_anchors = build_anchor_generator(cfg, input_shape).num_anchors[0]
+            assert list(cfg.MODEL.RPN.CONV_DIMS) == [-1]
+        self.conv = _Conv2d(in_channels, in_channels, 3)
+        self.objectness_logits = _Conv2d(in_channels, num_anchors, 1)
+        self.anchor_deltas = _Conv2d(in_channels, num_anchors * box_dim, 1)
+
+    def forward_nhwc(self, x):
+        t = layers.conv(x, self.conv.pw(), self.conv.bias, 1, 1, relu=True)
+        a = self.objectness_logits.weight.shape[0]
+        y = layers.fused_heads(t, [(self.objectness_logits.weight, self.objectness_logits.bias),
+                                   (self.anchor_deltas.weight, self.anchor_deltas.bias)])      # one GEMM, N = 5A (padded)
+        return y[..., :a], y[..., a:5 * a]     # NHWC f32: [N,H,W,A], [N,H,W,4A]
+
+    def forward(self, features):
+        lg, dl = self.forward_nhwc(to_nhwc(features[0]))
+        return [to_nchw(lg)], [to_nchw(dl)]
+
+
+# ------------------------------------------------------------------------------------------------ RPN
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class RPN(nn.Module):
+    def __init__(self, cfg, input_shape: Dict[str, object]):
+        super().__init__()
+        r = cfg.MODEL.RPN
+        self.in_features = r.IN_FEATURES
+        shapes = [input_shape[f] for f in self.in_features]
+        self.anchor_generator = build_anchor_generator(cfg, shapes)
+        self.rpn_head = RPN_HEAD_REGISTRY.get(r.HEAD_NAME)(cfg, shapes)
+        self.iou_thresholds, self.iou_labels = list(r.IOU_THRESHOLDS), list(r.IOU_LABELS)
+        self.batch_size_per_image, self.positive_fraction = r.BATCH_SIZE_PER_IMAGE, r.POSITIVE_FRACTION
+        self.pre_nms_topk = {True: r.PRE_NMS_TOPK_TRAIN, False: r.PRE_NMS_TOPK_TEST}
+        self.post_nms_topk = {True: r.POST_NMS_TOPK_TRAIN, False: r.POST_NMS_TOPK_TEST}
+        self.nms_thresh, self.min_box_size = r.NMS_THRESH, float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE)
+        self.weights = tuple(r.BBOX_REG_WEIGHTS)
+        self.smooth_l1_beta = r.SMOOTH_L1_BETA
+        assert r.BBOX_REG_LOSS_TYPE == "smooth_l1" and self.smooth_l1_beta == 0.0 and r.BOUNDARY_THRESH < 0
+        lw = r.LOSS_WEIGHT
+        self.loss_weight = {"loss_rpn_cls": lw, "loss_rpn_loc": lw * r.BBOX_REG_LOSS_WEIGHT}
+        self.sample_generator = torch.Generator()  # replayable CPU stream (seed it per rank: utils/env.py:27-46)
+        self.storage = {}
+
+    @torch.no_grad()
+    def label_and_sample_anchors(self, anchors, gt_instances):
+        """rpn.py:305-363 -> (labels int8 [N,A], matched gt boxes [N,A,4])."""
+        labels, matched = [], []
+        for gi in gt_instances:
+            gtb = gi.gt_boxes.tensor.float().contiguous()
+            idx, lab = hip.iou_match(gtb, anchors, self.iou_thresholds, self.iou_labels, True)
+            pos, neg = subsample_labels(lab, self.batch_size_per_image, self.positive_fraction, 0, self.sample_generator)
+            lab.fill_(-1)
+            lab[pos] = 1
+            lab[neg] = 0
+            labels.append(lab)
+            matched.append(torch.zeros_like(anchors) if len(gtb) == 0 else gtb[idx])
+        return labels, matched
+
+    def losses(self, anchors, logits, labels, deltas, matched):
+        """rpn.py:365-429 (+ _dense_box_regression_loss box_regression.py:229-270, smooth-L1 beta 0 = L1)."""
+        n = len(labels)
+        gl = torch.stack(labels)
+        pos = gl == 1
+        self.storage["rpn/num_pos_anchors"] = pos.sum() / n
+        self.storage["rpn/num_neg_anchors"] = (gl == 0).sum() / n
+        pi = torch.nonzero(pos, as_tuple=True)
+        gt_d = get_deltas(anchors[pi[1]], torch.stack(matched)[pi], self.weights)
+        loc = torch.abs(deltas[pi] - gt_d).sum()
+        valid = gl >= 0
+        obj = F.binary_cross_entropy_with_logits(logits[valid], gl[valid].to(torch.float32), reduction="sum")
+        norm = self.batch_size_per_image * n
+        out = {"loss_rpn_cls": obj / norm, "loss_rpn_loc": loc / norm}
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
+
+    @torch.no_grad()
+    def predict_proposals(self, logits, deltas, image_sizes, hf, wf):
+        """rpn.py:482-533 + find_top_rpn_proposals proposal_utils.py:22-130 for all images at once."""
+        N, total = logits.shape
+        training = self.training
+        topk = min(total, self.pre_nms_topk[training])
+        keys, order = hip.sort_desc(logits.detach().contiguous())
+        img_hw = torch.tensor(image_sizes, dtype=torch.int32, device=logits.device)
+        ag = self.anchor_generator
+        boxes, valid = hip.rpn_decode(order, deltas.detach().contiguous(), ag.cell_anchors_0, img_hw, hf, wf, topk,
+                                      float(ag.strides[0]), ag.offset, self.weights, SCALE_CLAMP, self.min_box_size)
+        post = self.post_nms_topk[training]
+        keep, nkeep = hip.nms(boxes, valid, self.nms_thresh, post)
+        bad = (valid == 2).any() | ~torch.isfinite(keys[:, :topk]).all()
+        host = torch.cat([nkeep, bad.to(torch.int32).view(1)]).tolist()      # the one host sync of this stage
+        if host[-1] and training:
+            raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")  # proposal_utils.py:100-105
+        out = []
+        for n in range(N):
+            k = keep[n, : host[n]].long()
+            inst = Instances(tuple(image_sizes[n]))
+            inst.proposal_boxes = Boxes(boxes[n][k])
+            inst.objectness_logits = keys[n][k]
+            out.append(inst)
+        return out
+
+    def forward_nhwc(self, image_sizes, res4, gt_instances=None):
+        N, hf, wf, _ = res4.shape
+        logits, deltas = self.rpn_head.forward_nhwc(res4)
+        lg = logits.reshape(N, -1)                # (N, Hi*Wi*A)   rpn.py:456-460
+        dl = deltas.reshape(N, -1, 4)             # (N, Hi*Wi*A, 4) rpn.py:461-467 (NHWC already has (h,w,a,b) order)
+        losses = {}
+        if self.training:
+            assert gt_instances is not None, "RPN requires gt_instances in training!"
+            anchors = self.anchor_generator.grid(hf, wf)
+            labels, matched = self.label_and_sample_anchors(anchors, gt_instances)
+            losses = self.losses(anchors, lg, labels, dl, matched)
+        proposals = self.predict_proposals(lg, dl, image_sizes, hf, wf)
+        return proposals, losses
+
+    def forward(self, images, features, gt_instances=None):
+        """rpn.py:431-480.  ``images`` needs ``.image_sizes``; features: dict of logical-NCHW maps."""
+        f = features[self.in_features[0]]
+        gts = None if gt_instances is None else [as_instances(g) for g in gt_instances]
+        return self.forward_nhwc(images.image_sizes, to_nhwc(f), gts)
+
+
+def build_proposal_generator(cfg, input_shape):
+    name = cfg.MODEL.PROPOSAL_GENERATOR.NAME
+    if name == "PrecomputedProposals":
+        return None
+    return PROPOSAL_GENERATOR_REGISTRY.get(name)(cfg, input_shape)
