@@ -1,0 +1,143 @@
+"""Benchmark of the CDDMSL training step on MI355X (BASELINE.json metric: images/sec of the train step).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): configs[1] of BASELINE.json -- VOC(labeled)+Clipart(unlabeled) CLIP RN50-C4 Faster R-CNN +
+caption consistency, 16 images/GPU of 800x1333, bf16 MFMA, iteration > 10000 so all three branches of
+``SimpleTrainer.run_step`` are live (supervised + image-level + region-level consistency, backward, gradient
+all-reduce, per-parameter clip + SGD).  Synthetic inputs and seeded random weights (no datasets/checkpoints offline);
+inputs are resident in HBM before the timed region.
+
+One JSON line on rank 0 with ``roofline`` (dominant kernel = the bf16 implicit-GEMM conv; achieved = algorithmic
+2*M*N*K FLOPs of its launches / their HIP-event durations, measured live over the timed steps on the launch stream)
+and ``cpu_baseline`` (the oracle = PyTorch-CPU restatement of the same step, a bounded sample timed on this box's
+host cores, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def make_cfg(dtype, kd=False):
+    from cddmsl_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "VOC-Experiments", "faster_rcnn_CLIP_R_50_C4.yaml"))
+    cfg.merge_from_list(["MODEL.COMPUTE_DTYPE", dtype, "MODEL.KD_REGULRAZIATION", kd])
+    return cfg
+
+
+def cpu_baseline(height, width, threads):
+    """Oracle (kind 'port'): one full training step (3 branches + backward + clip/SGD) on ONE image, CPU fp32."""
+    from cddmsl_amd import synthetic
+    from oracle import model as om
+    torch.set_num_threads(threads)
+    sd = synthetic.make_state_dict(0)
+    msd = synthetic.make_mapper_state_dict(1)
+    cfg = om.Cfg()
+    keys = om.trainable_keys(sd, cfg)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    batch = synthetic.make_batch(1, height, width)
+    t0 = time.perf_counter()
+    ld = om.run_step_losses(sd, msd, cfg, batch, 20000, torch.Generator().manual_seed(1))
+    sum(ld.values()).backward()
+    grads = {k: sd[k].grad for k in keys}
+    with torch.no_grad():
+        plain = {k: v.detach() for k, v in sd.items()}
+        om.sgd_step(plain, grads, {}, cfg, 20000)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"1 image {height}x{width}, 1 full step (3 branches, backward, clip+SGD), oracle fp32 on "
+                      f"{threads} host threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    from cddmsl_amd import engine, hip
+    rank, world = engine.init_distributed()
+    assert world == max(args.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    cfg = make_cfg(args.dtype)
+    cfg.MODEL.DEVICE = str(dev)
+
+    from cddmsl_amd import synthetic
+    from cddmsl_amd.modeling import TransformerMapper
+    tr = engine.build_trainer(cfg, args.batch, args.height, args.width)
+    tr.model.load_state_dict(synthetic.make_state_dict(0), strict=False)
+    tr.clipcap_model.load_state_dict(synthetic.make_mapper_state_dict(1))
+    tr.iter = 20000          # past burn-in (train_loop.py:334): every branch is computed AND contributes gradients
+    tr.metrics_period = 0    # no per-step host sync inside the timed region (losses stay on device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.run_step()
+    barrier()
+    hip.PROFILE.enable()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = tr.run_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = hip.PROFILE.collect()
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    losses = {k: float(v) for k, v in last.items()}
+
+    if rank == 0:
+        gb = args.batch * world
+        dom = prof.get("conv_fwd", {"flops": 0.0, "ms": 0.0, "launches": 0})
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        out = {
+            "metric": "images/sec (train step) VOC+Clipart RN50-C4", "value": gb * args.steps / dt, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "faster_rcnn_voc.sh VOC(labeled)+Clipart(unlabeled) CLIP RN50-C4 + caption consistency "
+                                   f"(iter>10000: supervised + image-level + region-level), {args.batch} img/GPU "
+                                   f"{args.height}x{args.width}, synthetic pixels + seeded random weights",
+                       "global_batch": gb, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "kernel": "k_conv_fwd (implicit-GEMM conv/linear fwd+dgrad)", "achieved": ach,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "launches_per_step": dom["launches"] / max(args.steps, 1),
+                         "kernel_ms_per_step": dom["ms"] / max(args.steps, 1)},
+            "kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in prof.items()},
+            "kernels_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["ms"] > 0 and v["flops"] > 0},
+            "losses": losses,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
+            out["cpu_baseline"] = cpu_baseline(args.height, args.width, threads)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,58 @@ def _L():
     return L
 
 
+class _Profiler:
+    """Optional per-kernel timing with HIP events recorded on the launch stream (torch's current stream is the
+    stream every kernel of this library is enqueued on).  Used by bench.py for the roofline object."""
+
+    def __init__(self):
+        self.on = False
+        self.events = []
+
+    def enable(self):
+        self.on, self.events = True, []
+
+    def begin(self):
+        if not self.on:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, e0, name, flops=0.0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.events.append((name, flops, e0, e1))
+
+    def collect(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.events:
+            d = out.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0})
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+            d["launches"] += 1
+        self.on, self.events = False, []
+        return out
+
+
+PROFILE = _Profiler()
+
+
+def _timed(name):
+    def deco(fn):
+        def wrapper(*a, **k):
+            e0 = PROFILE.begin()
+            r = fn(*a, **k)
+            PROFILE.end(e0, name)
+            return r
+        wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+        return wrapper
+    return deco
+
+
 def _dt(t):
     if t.dtype not in DT:
         raise TypeError(f"unsupported dtype {t.dtype}: the kernels compute in bf16 or f32")
@@ -77,10 +129,12 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
     for v in (residual, relu_mask):
         assert v is None or (v.dtype == x.dtype and v.is_contiguous() and v.numel() == y.numel())
+    e0 = PROFILE.begin()
     st = _L().cddmsl_conv_fwd(ptr(x), ptr(w), ptr(y), ptr(scale), ptr(bias), ptr(residual), ptr(relu_mask),
                               N, H, W, Cin, Cout, KH, KW, stride, pad, int(pool), Cout, Cout, Cout,
                               int(relu), int(out_f32), _dt(x), stream_ptr())
     check(st, "cddmsl_conv_fwd")
+    PROFILE.end(e0, "conv_fwd", 2.0 * N * Ho * Wo * Cout * KH * KW * Cin)   # algorithmic 2*M*N*K
     return y
 
 
@@ -104,12 +158,15 @@ def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None
     if out is None:
         out = torch.zeros(w_shape, device=x.device, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(w_shape)
+    e0 = PROFILE.begin()
     st = _L().cddmsl_conv_wgrad(ptr(x), ptr(dy), ptr(out), ptr(scale), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                 int(pool), Cout, _dt(x), stream_ptr())
     check(st, "cddmsl_conv_wgrad")
+    PROFILE.end(e0, "conv_wgrad", 2.0 * (dy.numel() // Cout) * Cout * KH * KW * Cin)
     return out
 
 
+@_timed("weight_prep")
 def weight_prep(w_master, scale, dtype, want_fwd=True, want_dgrad=True):
     """f32 master [Cout,KH,KW,Cin] -> (fwd weights, dgrad weights [Cin,KH,KW,Cout] flipped, *scale[cout])."""
     require_cuda(w_master, scale)
@@ -127,6 +184,7 @@ def _f3(v):
     return (c_float * 3)(*[float(x) for x in v])
 
 
+@_timed("preprocess")
 def preprocess(images_u8, Hp, Wp, mean, std, dtype, Cp=None):
     """list of u8 CHW device tensors -> normalised, zero-padded NHWC [N,Hp,Wp,Cp] (rcnn.py:758-768)."""
     require_cuda(*images_u8)
@@ -140,6 +198,7 @@ def preprocess(images_u8, Hp, Wp, mean, std, dtype, Cp=None):
     return out
 
 
+@_timed("preprocess224")
 def preprocess224(images_u8, Hp, Wp, mean, std, dtype, size=224, Cp=None):
     """rcnn.py:161-179: /255 -> pad to (Hp,Wp) -> bicubic short side `size` -> center crop -> normalise; NHWC out."""
     require_cuda(*images_u8)
@@ -158,6 +217,7 @@ def preprocess224(images_u8, Hp, Wp, mean, std, dtype, size=224, Cp=None):
     return out
 
 
+@_timed("avgpool2_fwd")
 def avgpool2_fwd(x):
     require_cuda(x)
     N, H, W, C = x.shape
@@ -166,6 +226,7 @@ def avgpool2_fwd(x):
     return y
 
 
+@_timed("avgpool2_bwd")
 def avgpool2_bwd(dy, in_shape, mask=None, add=None):
     """dx = up(dy)/4 (+ add), zeroed where mask <= 0.  in_shape = (N,H,W,C) of the pooled tensor's input."""
     require_cuda(dy, mask, add)
@@ -176,6 +237,7 @@ def avgpool2_bwd(dy, in_shape, mask=None, add=None):
     return dx
 
 
+@_timed("attn_tokens_fwd")
 def attn_tokens_fwd(x, pos):
     """x [K,P,C] (T), pos [P+1,C] f32 -> tok [K,P+1,C]"""
     require_cuda(x, pos)
@@ -186,6 +248,7 @@ def attn_tokens_fwd(x, pos):
     return tok
 
 
+@_timed("attn_tokens_bwd")
 def attn_tokens_bwd(dtok):
     require_cuda(dtok)
     K, P1, C = dtok.shape
@@ -194,6 +257,7 @@ def attn_tokens_bwd(dtok):
     return dx
 
 
+@_timed("relu_bwd")
 def relu_bwd(g, y):
     """dx = g * (y > 0) in y's dtype; g may be f32 while y is bf16."""
     require_cuda(g, y)
@@ -205,6 +269,7 @@ def relu_bwd(g, y):
     return dx
 
 
+@_timed("colsum")
 def colsum(x2d, period=1, out=None):
     """f32 column sums of x [rows, cols] (rows folded modulo `period`)."""
     require_cuda(x2d, out)
@@ -221,6 +286,7 @@ def same_layout(a, b):
     return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
 
 
+@_timed("sgd_clip_step")
 def sgd_clip_step(params, grads, moms, norm_ws, lr, momentum, wd, clip, first_step):
     """Fused per-parameter grad-norm clip + SGD(momentum, wd) over a list of f32 tensors (solver/build.py:59-130)."""
     n = len(params)
@@ -239,6 +305,7 @@ def sgd_clip_step(params, grads, moms, norm_ws, lr, momentum, wd, clip, first_st
 
 
 # ------------------------------------------------------------------------------------------------ RoIAlign
+@_timed("roi_align_forward")
 def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, dbg_grid=None):
     """x NHWC [N,H,W,C]; rois [K,5] f32 (batch_idx,x0,y0,x1,y1) -> [K,ph,pw,C]  (layers/roi_align.py:49-65)."""
     require_cuda(x, rois)
@@ -251,6 +318,7 @@ def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, d
     return y
 
 
+@_timed("roi_align_backward")
 def roi_align_backward(dy, rois, roi_start, in_shape, spatial_scale, sampling_ratio, aligned):
     """dy [K,ph,pw,C] -> dx NHWC in_shape.  rois must be grouped by image; roi_start int32 [N+1] prefix offsets."""
     require_cuda(dy, rois, roi_start)
@@ -279,6 +347,7 @@ def anchors(cell, Hf, Wf, stride, offset):
 _sort_ws = {}
 
 
+@_timed("sort_desc")
 def sort_desc(keys):
     """Stable descending sort of each row of keys [N,total] f32 -> (sorted keys, int32 order)."""
     require_cuda(keys)
@@ -298,6 +367,7 @@ def sort_desc(keys):
     return keys_out, order
 
 
+@_timed("rpn_decode")
 def rpn_decode(order, deltas, cell, img_hw, Hf, Wf, topk, stride, offset, weights, scale_clamp, min_size):
     """Decode + clip the top-k sorted anchors of every image -> boxes [N,topk,4] f32, valid u8 [N,topk]."""
     require_cuda(order, deltas, cell, img_hw)
@@ -312,6 +382,7 @@ def rpn_decode(order, deltas, cell, img_hw, Hf, Wf, topk, stride, offset, weight
     return boxes, valid
 
 
+@_timed("nms")
 def nms(boxes, valid, thr, max_keep):
     """boxes [N,n,4] f32 score-descending, valid u8 [N,n] -> keep int32 [N,max_keep] (positions), nkeep int32 [N]."""
     require_cuda(boxes, valid)
@@ -325,6 +396,7 @@ def nms(boxes, valid, thr, max_keep):
     return keep, nkeep
 
 
+@_timed("iou_match")
 def iou_match(gt, preds, thresholds, labels, allow_low_quality):
     """Fused pairwise_iou + Matcher for one image: gt [G,4], preds [P,4] -> (matches int64 [P], labels int8 [P])."""
     require_cuda(gt, preds)
@@ -343,6 +415,7 @@ def iou_match(gt, preds, thresholds, labels, allow_low_quality):
 
 
 # ------------------------------------------------------------------------------------------------ attention pool / losses
+@_timed("attnpool_core_fwd")
 def attnpool_core_fwd(q0, kv, heads):
     require_cuda(q0, kv)
     K, C = q0.shape
@@ -355,6 +428,7 @@ def attnpool_core_fwd(q0, kv, heads):
     return o, p
 
 
+@_timed("attnpool_core_bwd")
 def attnpool_core_bwd(dO, q0, kv, p, heads):
     require_cuda(dO, q0, kv, p)
     K, C = q0.shape
