@@ -1,0 +1,106 @@
+/*
+ * cddmsl_hip.h -- C-ABI of libcddmsl_hip.so, the MI355X (gfx950) kernels of the CDDMSL training hot path.
+ *
+ * Boundary: the reference reaches its native ops through torch.autograd.Function wrappers over
+ * `_C.<op>_forward/_backward(Tensor..., scalars...)` (detectron2/layers/roi_align_rotated.py:11-47; the pybind
+ * file csrc/vision.cpp is absent from the tree) and through torchvision/ATen for the hot path.  This header is
+ * the plain-C equivalent: device pointers + sizes + the HIP stream to enqueue on, no torch types.  Every function
+ * returns 0 on success (1 = bad argument, 2 = launch failure), never synchronises, owns no memory (the caller
+ * allocates outputs and workspaces) and keeps no global mutable state, so calls are re-entrant and stream-ordered.
+ *
+ * Conventions
+ *   dtype      0 = bf16 (throughput path), 1 = f32 (exact-f32 MFMA parity path)
+ *   activations NHWC [N][H][W][C] in `dtype`; C * sizeof(dtype) must be a multiple of 16 bytes
+ *   weights    [Cout][KH][KW][Cin] (= torch channels_last OIHW); f32 masters, `dtype` prepared copies
+ *   rois       [K][5] f32 (batch_idx, x0, y0, x1, y1), grouped by image
+ *   stream     hipStream_t passed as void*
+ * Paths below are relative to /root/reference/detectron2/.
+ */
+#ifndef CDDMSL_HIP_H
+#define CDDMSL_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int cddmsl_abi_version(void);
+int cddmsl_probe_axpb(const float* x, float* y, float a, float b, long n, void* stream);
+
+/* ---- implicit-GEMM convolution / linear (bf16 or exact-f32 MFMA) ----------------------------------------------
+ * replaces ATen conv2d / F.linear + FrozenBatchNorm2d + ReLU (+ residual add, + AvgPool2d) as called from
+ * modeling/backbone/clip_backbone.py:57-70,193-219, layers/batch_norm.py:45-66,
+ * modeling/proposal_generator/rpn.py:158-177, modeling/backbone/clipcap/clipcap.py:39-163.
+ * y[m][n] = relu?( acc*scale[n] + bias[n] + residual[m][n] ), zeroed where relu_mask[m][n] <= 0 (ReLU backward);
+ * pool=1: 1x1 conv over the 2x2 average-pooled input.  dgrad = the same entry point on weight_prep's w_dgrad. */
+int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias, const void* residual,
+                    const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                    int pool, int ldy, int ldr, int ldm, int relu, int out_f32, int dtype, void* stream);
+/* dW[n][k] (f32, accumulated) += scale[n] * sum_m dY[m][n] * im2col(x)[m][k] */
+int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const float* scale, int Nimg, int Hi, int Wi, int Cin,
+                      int Cout, int KH, int KW, int stride, int pad, int pool, int ldd, int dtype, void* stream);
+/* f32 master -> `dtype` forward weights and flipped/transposed dgrad weights scaled by the FrozenBN scale */
+int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int Cout, int KH, int KW, int Cin,
+                       int dtype, void* stream);
+
+/* ---- RoIAlign  (layers/roi_align.py:49-65 -> torchvision.ops.roi_align; modeling/poolers.py:190-229) --------- */
+int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, int* dbg_grid, int N, int C, int H, int W, int K,
+                             int ph, int pw, float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
+int cddmsl_roi_align_backward(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay, float* ws_ax,
+                              int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw, float spatial_scale,
+                              int sampling_ratio, int aligned, int dtype, void* stream);
+
+/* ---- RPN / matcher index stages --------------------------------------------------------------------------------
+ * modeling/anchor_generator.py:161-228, modeling/box_regression.py:77-115, modeling/proposal_generator/rpn.py:514-533,
+ * modeling/proposal_generator/proposal_utils.py:22-130, layers/nms.py:19-39 (torchvision nms),
+ * structures/boxes.py:322-367 + modeling/matcher.py:61-126 */
+int cddmsl_anchors(const float* cell, float* out, int Hf, int Wf, int A, float stride, float offset, void* stream);
+int cddmsl_sort_desc(const float* keys_in, float* keys_out, int* idx_scratch, int* order_out, const int* offsets, int N,
+                     int total, void* temp, size_t* temp_bytes, void* stream);
+int cddmsl_rpn_decode(const int* order, const float* deltas, const float* cell, const int* img_hw, float* boxes,
+                      unsigned char* valid, int N, int Hf, int Wf, int A, int topk, float stride, float offset, float wx,
+                      float wy, float ww, float wh, float scale_clamp, float min_size, void* stream);
+int cddmsl_nms(const float* boxes, const unsigned char* valid, unsigned long long* mask_ws, int* keep, int* nkeep, int N,
+               int n, float thr, int max_keep, void* stream);
+int cddmsl_iou_match(const float* gt, int G, const float* preds, int P, long* matches, signed char* labels,
+                     unsigned int* best_ws, int nthr, float t0, float t1, int l0, int l1, int l2, int allow_low_quality,
+                     void* stream);
+
+/* ---- CLIP attention pool, query-0-only core  (modeling/backbone/clip_backbone.py:83-107) ---------------------- */
+int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int C, int dtype, void* stream);
+int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, int C, int dtype, void* stream);
+int cddmsl_attnpool_core_fwd(const void* q0, const void* kv, void* o, float* p, int K, int T, int H, float scale, int dtype,
+                             void* stream);
+int cddmsl_attnpool_core_bwd(const void* dO, const void* q0, const void* kv, const float* p, void* dq0, void* dkv, int K,
+                             int T, int H, float scale, int dtype, void* stream);
+
+/* ---- fp32 heads: cosine-logit classifier (modeling/roi_heads/fast_rcnn.py:546-572) and the contrastive loss over
+ * the cosine-similarity matrix (modeling/meta_arch/rcnn.py:308-317,458-468) ------------------------------------ */
+int cddmsl_l2norm_fwd(const float* x, float* y, float* inv, long R, int D, float eps, void* stream);
+int cddmsl_l2norm_bwd(const float* dy, const float* y, const float* inv, float* dx, long R, int D, void* stream);
+int cddmsl_cosine_logits_fwd(const float* x, const float* wn, float* scores, float* inv, long R, int D, int Kc,
+                             float temperature, float eps, void* stream);
+int cddmsl_cosine_logits_bwd(const float* ds, const float* x, const float* wn, const float* inv, float* dx, long R, int D,
+                             int Kc, float temperature, int accumulate, void* stream);
+int cddmsl_contrastive_fwd(const float* S, float* rlse, float* clse, float* loss, int n, int ld, void* stream);
+int cddmsl_contrastive_bwd(const float* S, const float* rlse, const float* clse, const float* gloss, float* dS, int n, int ld,
+                           void* stream);
+
+/* ---- elementwise: preprocessing (modeling/meta_arch/rcnn.py:161-179,758-768, structures/image_list.py:72-124),
+ * AvgPool2d(2) (clip_backbone.py:36,46,147), ReLU backward, column sums, fused clip+SGD (solver/build.py:59-130) -- */
+int cddmsl_preprocess(const unsigned char* img, void* out, int n, int h, int w, int Hp, int Wp, int Cp, const float* mean3,
+                      const float* std3, int dtype, void* stream);
+int cddmsl_preprocess224(const unsigned char* img, void* out, int n, int h, int w, int Hp, int Wp, int RH, int RW, int top,
+                         int left, int S, int Cp, const float* mean3, const float* std3, int dtype, void* stream);
+int cddmsl_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int cddmsl_avgpool2_bwd(const void* dy, const void* mask, const void* add, void* dx, int N, int H, int W, int C, int dtype,
+                        void* stream);
+int cddmsl_relu_bwd(const void* g, const void* y, void* dx, long numel, int g_f32, int dtype, void* stream);
+int cddmsl_colsum(const void* x, float* out, long rows, int cols, int period, int dtype, void* stream);
+int cddmsl_sgd_clip_step(float** params, const float** grads, float** moms, const long* sizes, int count, float* norm_ws,
+                         float lr, float momentum, float wd, float clip, int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDDMSL_HIP_H */
