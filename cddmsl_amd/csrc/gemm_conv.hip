@@ -68,6 +68,18 @@ template <> struct Mma<float> {
   __device__ static __forceinline__ void store(char* p, float v) { *(float*)p = v; }
 };
 
+// 8 consecutive elements (16 B of bf16 / 32 B of f32) -> floats
+template <typename T> __device__ __forceinline__ void load8(const char* p, float* f);
+template <> __device__ __forceinline__ void load8<__bf16>(const char* p, float* f) {
+  const u32x4 v = *(const u32x4*)p;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f(v[j] & 0xffff); f[2 * j + 1] = bf2f(v[j] >> 16); }
+}
+template <> __device__ __forceinline__ void load8<float>(const char* p, float* f) {
+  const f32x4 a = ((const f32x4*)p)[0], b = ((const f32x4*)p)[1];
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+
 __device__ __forceinline__ int swz(int row, int chunk) { return row * KCH + (chunk ^ ((row >> 1) & 7)); }
 
 // average of 4 packed chunks (2x2 avg-pool fused into the A loader)
@@ -183,7 +195,74 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
     __syncthreads();
   }
 
-  // epilogue: C/D map of the 32x32 MFMA: col = lane&31 (n), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (m)
+  // ---------------------------------------------------------------------------------------------
+  // epilogue.  C/D map of the 32x32 MFMA: col = lane&31 (n), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (m).
+  // Vector path (all leading dims multiples of 8): each wave transposes its accumulators through LDS
+  // (32 rows x 64 cols f32 per pass, 32-byte column groups XOR-swizzled by row) so that every lane owns
+  // 8 consecutive channels of one pixel: residual / mask are read and y is written 16-32 B per lane,
+  // whole 128-B lines per 8 lanes -- the scalar path issued 64 two-byte stores per lane instead.
+  const bool vec_ok = (p.Cout % 8 == 0) && (p.ldy % 8 == 0) && (!p.residual || p.ldr % 8 == 0) && (!p.relu_mask || p.ldm % 8 == 0);
+  if (vec_ok) {
+    float* ep = (float*)&lds[0][0] + wv * 2048;      // 8 KB per wave; the K-loop's last barrier already passed
+    const int cg = lane & 7, rr = lane >> 3;
+    const int n = n0 + wn * 64 + cg * 8;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = (p.scale && n + j < p.Cout) ? p.scale[n + j] : 1.f;
+      bi[j] = (p.bias && n + j < p.Cout) ? p.bias[n + j] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          int row = (g & 3) + 8 * (g >> 2) + 4 * h, col = b * 32 + r;
+          ep[row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7))] = acc[a][b][g];
+        }
+      __syncthreads();
+      if (n < p.Cout) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int row = rr + 8 * i;
+          int m = m0 + wm * 64 + a * 32 + row;
+          if (m >= p.M) continue;
+          const f32x4* src = (const f32x4*)(ep + row * 64 + ((cg ^ (row & 7)) << 3));
+          f32x4 v0 = src[0], v1 = src[1];
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+          if (p.residual) {
+            float rv[8];
+            load8<T>(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES, rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rv[j];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (p.relu_mask) {
+            float mv[8];
+            load8<T>(p.relu_mask + ((long)m * p.ldm + n) * Mma<T>::ES, mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
+          }
+          if (p.out_f32 || Mma<T>::ES == 4) {
+            f32x4* dst = (f32x4*)(p.y + ((long)m * p.ldy + n) * 4);
+            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            dst[0] = o0; dst[1] = o1;
+          } else {
+            u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            *(u32x4*)(p.y + ((long)m * p.ldy + n) * 2) = o;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     int n = n0 + wn * 64 + b * 32 + r;

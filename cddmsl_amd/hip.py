@@ -58,9 +58,10 @@ class _Profiler:
     def __init__(self):
         self.on = False
         self.events = []
+        self.shapes = []
 
     def enable(self):
-        self.on, self.events = True, []
+        self.on, self.events, self.shapes = True, [], []
 
     def begin(self):
         if not self.on:
@@ -69,12 +70,25 @@ class _Profiler:
         e.record()
         return e
 
-    def end(self, e0, name, flops=0.0):
+    def end(self, e0, name, flops=0.0, shape=None):
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.events.append((name, flops, e0, e1))
+        if shape is not None:
+            self.shapes.append((name, shape, flops, e0, e1))
+
+    def by_shape(self):
+        """(name, shape) -> [launches, ms, flops]; call before collect()."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, shape, flops, e0, e1 in self.shapes:
+            d = out.setdefault((name, shape), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += flops
+        return out
 
     def collect(self):
         torch.cuda.synchronize()
@@ -134,7 +148,8 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
                               N, H, W, Cin, Cout, KH, KW, stride, pad, int(pool), Cout, Cout, Cout,
                               int(relu), int(out_f32), _dt(x), stream_ptr())
     check(st, "cddmsl_conv_fwd")
-    PROFILE.end(e0, "conv_fwd", 2.0 * N * Ho * Wo * Cout * KH * KW * Cin)   # algorithmic 2*M*N*K
+    PROFILE.end(e0, "conv_fwd", 2.0 * N * Ho * Wo * Cout * KH * KW * Cin,    # algorithmic 2*M*N*K
+                (N * Ho * Wo, Cout, KH * KW * Cin, KH, int(pool), stride))
     return y
 
 
@@ -162,7 +177,8 @@ def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None
     st = _L().cddmsl_conv_wgrad(ptr(x), ptr(dy), ptr(out), ptr(scale), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                 int(pool), Cout, _dt(x), stream_ptr())
     check(st, "cddmsl_conv_wgrad")
-    PROFILE.end(e0, "conv_wgrad", 2.0 * (dy.numel() // Cout) * Cout * KH * KW * Cin)
+    PROFILE.end(e0, "conv_wgrad", 2.0 * (dy.numel() // Cout) * Cout * KH * KW * Cin,
+                (dy.numel() // Cout, Cout, KH * KW * Cin, KH, int(pool), stride))
     return out
 
 
@@ -326,9 +342,9 @@ def roi_align_backward(dy, rois, roi_start, in_shape, spatial_scale, sampling_ra
     K, ph, pw, _ = dy.shape
     assert roi_start.dtype == torch.int32 and roi_start.numel() == N + 1 and dy.is_contiguous()
     dx = torch.empty(in_shape, device=dy.device, dtype=dy.dtype)
-    ay = torch.empty(max(K, 1) * H * ph, device=dy.device, dtype=torch.float32)
-    ax = torch.empty(max(K, 1) * W * pw, device=dy.device, dtype=torch.float32)
-    fp = torch.empty(max(K, 1) * 4, device=dy.device, dtype=torch.int32)
+    ay = workspace("roi_ay", max(K, 1) * H * ph * 4, dy.device)
+    ax = workspace("roi_ax", max(K, 1) * W * pw * 4, dy.device)
+    fp = workspace("roi_fp", max(K, 1) * 16, dy.device)
     check(_L().cddmsl_roi_align_backward(ptr(dy), ptr(rois), ptr(roi_start), ptr(dx), ptr(ay), ptr(ax), ptr(fp), N, C, H, W, K,
                                           ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(dy), stream_ptr()),
           "cddmsl_roi_align_backward")
@@ -344,7 +360,18 @@ def anchors(cell, Hf, Wf, stride, offset):
     return out
 
 
-_sort_ws = {}
+_WS = {}
+
+
+def workspace(key, nbytes, device):
+    """Persistent scratch buffers (NMS masks, sort temp storage ...): allocated once per (key, size) and reused, so the
+    hot loop never goes back to the allocator for its 100+ MB workspaces."""
+    k = (key, str(device))
+    buf = _WS.get(k)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 16), device=device, dtype=torch.uint8)
+        _WS[k] = buf
+    return buf
 
 
 @_timed("sort_desc")
@@ -361,7 +388,7 @@ def sort_desc(keys):
     nbytes = ctypes.c_size_t(0)
     check(_L().cddmsl_sort_desc(ptr(keys), ptr(keys_out), ptr(idx), ptr(order), ptr(offs), N, total, None, ctypes.byref(nbytes),
                                 stream_ptr()), "cddmsl_sort_desc(size)")
-    ws = torch.empty(max(int(nbytes.value), 16), device=dev, dtype=torch.uint8)
+    ws = workspace("sort", nbytes.value, dev)
     check(_L().cddmsl_sort_desc(ptr(keys), ptr(keys_out), ptr(idx), ptr(order), ptr(offs), N, total, ptr(ws), ctypes.byref(nbytes),
                                 stream_ptr()), "cddmsl_sort_desc")
     return keys_out, order
@@ -389,7 +416,7 @@ def nms(boxes, valid, thr, max_keep):
     N, n, _ = boxes.shape
     assert boxes.dtype == torch.float32 and boxes.is_contiguous() and valid.dtype == torch.uint8 and valid.is_contiguous()
     nw = (n + 63) // 64
-    mask = torch.empty(max(N * n * nw, 1), device=boxes.device, dtype=torch.int64)
+    mask = workspace("nms_mask", max(N * n * nw, 1) * 8, boxes.device)
     keep = torch.full((N, max_keep), -1, device=boxes.device, dtype=torch.int32)
     nkeep = torch.zeros(N, device=boxes.device, dtype=torch.int32)
     check(_L().cddmsl_nms(ptr(boxes), ptr(valid), ptr(mask), ptr(keep), ptr(nkeep), N, n, thr, max_keep, stream_ptr()), "cddmsl_nms")

@@ -167,6 +167,8 @@ class BlockParams:
 
 
 def _block_forward(x, bp, save):
+    """Bottleneck forward (clip_backbone.py:57-70).  AvgPool2d(stride) runs as its own HBM-bound kernel: fusing it into
+    the GEMM A-loader (kernel option pool=1, kept and tested) halves the MFMA rate of this kernel structure."""
     T = x.dtype
     (s1, b1), (s2, b2), (s3, b3), bnd = bp.bn
     w1, _ = bp.pw[0].get(T, False)
@@ -175,16 +177,18 @@ def _block_forward(x, bp, save):
     pool = bp.stride > 1
     o1 = hip.conv_fwd(x, w1, s1, b1, relu=True)
     o2 = hip.conv_fwd(o1, w2, s2, b2, relu=True, pad=1)
+    p2 = hip.avgpool2_fwd(o2) if pool else o2
+    px = hip.avgpool2_fwd(x) if pool else x
     if bp.pw[3] is not None:
         wd, _ = bp.pw[3].get(T, False)
-        idn = hip.conv_fwd(x, wd, bnd[0], bnd[1], pool=pool)
+        idn = hip.conv_fwd(px, wd, bnd[0], bnd[1])
     else:
         idn = x
-    out = hip.conv_fwd(o2, w3, s3, b3, residual=idn, relu=True, pool=pool)
-    return out, ((o1, o2) if save else None)
+    out = hip.conv_fwd(p2, w3, s3, b3, residual=idn, relu=True)
+    return out, ((o1, o2, p2 if pool else None, px if pool else None) if save else None)
 
 
-def _block_backward(gs, x, o1, o2, bp, need_dx, mask_x):
+def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x):
     """gs = dL/d(pre-ReLU sum) of this block (already masked by out>0).  Returns dL/dx, masked by x>0 when
     ``mask_x`` (x is the previous block's post-ReLU output) so it is directly the previous block's ``gs``."""
     T = x.dtype
@@ -192,7 +196,7 @@ def _block_backward(gs, x, o1, o2, bp, need_dx, mask_x):
     pool = bp.stride > 1
     w1p, w2p, w3p, wdp = bp.w
     shp = lambda w: _ohwi(w).shape
-    hip.conv_wgrad(o2, gs, shp(w3p), s3, pool=pool, out=_ohwi(_grad_buf(w3p)))
+    hip.conv_wgrad(p2 if pool else o2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
     _, w3d = bp.pw[2].get(T, True)
     if pool:
         dp2 = hip.conv_fwd(gs, w3d)
@@ -204,7 +208,7 @@ def _block_backward(gs, x, o1, o2, bp, need_dx, mask_x):
     dpre1 = hip.conv_fwd(dpre2, w2d, pad=1, relu_mask=o1)
     hip.conv_wgrad(x, dpre1, shp(w1p), s1, out=_ohwi(_grad_buf(w1p)))
     if wdp is not None:
-        hip.conv_wgrad(x, gs, shp(wdp), bnd[0], pool=pool, out=_ohwi(_grad_buf(wdp)))
+        hip.conv_wgrad(px if pool else x, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
     if not need_dx:
         return None
     if wdp is not None:
@@ -225,7 +229,7 @@ class ResStageFn(torch.autograd.Function):
         cur = x
         for bp in blocks:
             cur, mids = _block_forward(cur, bp, True)
-            saved += [mids[0], mids[1], cur]
+            saved += [mids[0], mids[1], mids[2], mids[3], cur]
         ctx.blocks = blocks
         ctx.save_for_backward(*saved)
         return cur
@@ -237,8 +241,8 @@ class ResStageFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         gs = hip.relu_bwd(g.contiguous(), saved[-1])   # mask by the stage output's ReLU
         for i in range(len(blocks) - 1, -1, -1):
-            x, o1, o2 = saved[3 * i], saved[3 * i + 1], saved[3 * i + 2]
-            gs = _block_backward(gs, x, o1, o2, blocks[i], need_dx or i > 0, mask_x=i > 0)
+            x, o1, o2, p2, px = saved[5 * i: 5 * i + 5]
+            gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0)
         return gs, None, None
 
 
