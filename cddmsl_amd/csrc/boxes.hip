@@ -89,7 +89,8 @@ __global__ void k_nms_mask(const float* boxes, unsigned long long* mask, int n, 
   }
   mask[((long)img * n + i) * nw + cb] = bits;
 }
-// one wave per image: lanes hold the `removed` words; scan rows in order.
+// one wave per image: lanes hold the `removed` words (pre-seeded with the invalid boxes, so the scan loop touches
+// global memory only for boxes it keeps); scan rows in order.
 __global__ void k_nms_scan(const unsigned long long* mask, const unsigned char* valid, int* keep, int* nkeep, int n, int nw,
                            int max_keep) {
   int img = blockIdx.x, lane = threadIdx.x;
@@ -98,7 +99,17 @@ __global__ void k_nms_scan(const unsigned long long* mask, const unsigned char* 
   constexpr int WPL = 8;  // words per lane -> up to 64*8*64 = 32768 boxes
   unsigned long long removed[WPL];
 #pragma unroll
-  for (int q = 0; q < WPL; ++q) removed[q] = 0;
+  for (int q = 0; q < WPL; ++q) {
+    unsigned long long bits = 0;
+    int ww = q * 64 + lane;
+    if (ww < nw) {
+      for (int b = 0; b < 64; ++b) {
+        int i = ww * 64 + b;
+        if (i >= n || v[i] != 1) bits |= 1ull << b;
+      }
+    }
+    removed[q] = bits;
+  }
   int cnt = 0;
   for (int i = 0; i < n && cnt < max_keep; ++i) {
     int w = i >> 6;
@@ -106,8 +117,7 @@ __global__ void k_nms_scan(const unsigned long long* mask, const unsigned char* 
 #pragma unroll
     for (int q = 0; q < WPL; ++q) if ((w >> 6) == q) word = removed[q];
     word = __shfl(word, w & 63, 64);
-    bool dead = ((word >> (i & 63)) & 1ull) || v[i] != 1;
-    if (dead) continue;      // uniform
+    if ((word >> (i & 63)) & 1ull) continue;      // uniform
     if (lane == 0) keep[(long)img * max_keep + cnt] = i;
     ++cnt;
 #pragma unroll

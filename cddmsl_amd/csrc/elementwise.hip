@@ -203,22 +203,23 @@ __global__ void k_relu_bwd(const char* g, const char* y, char* dx, long nchunks,
   }
 }
 
-// column sums: out[c] (f32) += sum_r x[r][c]  (bias grads, positional-embedding grads with row period)
+// column sums: out[(r % period)][c] (f32) += sum_r x[r][c]  (bias grads; positional-embedding grads with period 50).
+// grid.x = 64-column blocks, grid.y = row slabs, grid.z = residue (period); each thread walks the rows of its residue
+// inside the slab and issues ONE atomic.
 template <typename T>
-__global__ void k_colsum(const char* x, float* out, long rows, int cols, int period) {
-  // grid.x over column blocks of 64, grid.y over row slabs; out index = (r % period) * cols + c
+__global__ void k_colsum(const char* x, float* out, long rows, int cols, int period, int slab) {
   int c = blockIdx.x * 64 + (threadIdx.x & 63);
   int rlane = threadIdx.x >> 6;           // 4 row lanes
-  long r0 = (long)blockIdx.y * 256;
-  if (c >= cols) return;
-  if (period == 1) {
-    float s = 0.f;
-    for (long r = r0 + rlane; r < min(rows, r0 + 256); r += 4) s += Elt<T>::ld(x + (r * cols + c) * Elt<T>::ES);
-    atomicAdd(out + c, s);
-  } else {
-    for (long r = r0 + rlane; r < min(rows, r0 + 256); r += 4)
-      atomicAdd(out + (r % period) * cols + c, Elt<T>::ld(x + (r * cols + c) * Elt<T>::ES));
-  }
+  int res = blockIdx.z;
+  long j0 = (long)blockIdx.y * slab;      // index within the residue class: row = res + period * j
+  long nj = (rows - res + period - 1) / period;
+  float s = 0.f;
+  if (c < cols)
+    for (long j = j0 + rlane; j < min(nj, j0 + slab); j += 4) s += Elt<T>::ld(x + ((res + period * j) * cols + c) * Elt<T>::ES);
+  __shared__ float red[4][64];
+  red[rlane][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rlane == 0 && c < cols) atomicAdd(out + (long)res * cols + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ---------------------------------------------------------------- fused clip + SGD (multi-tensor, 2 passes)
@@ -343,8 +344,12 @@ extern "C" int cddmsl_relu_bwd(const void* g, const void* y, void* dx, long nume
 extern "C" int cddmsl_colsum(const void* x, float* out, long rows, int cols, int period, int dtype, void* stream) {
   if (rows < 0 || cols <= 0 || period <= 0) return CDDMSL_ERR_ARG;
   if (rows == 0) return CDDMSL_OK;
-  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 255) / 256));
-  DISPATCH(dtype, k_colsum, <<<grid, dim3(256), 0, (hipStream_t)stream>>>((const char*)x, out, rows, cols, period));
+  if (period > 65535) return CDDMSL_ERR_ARG;
+  long nj = (rows + period - 1) / period;
+  int slab = 256;
+  while ((nj + slab - 1) / slab > 2048) slab *= 2;      // keep the grid modest; rows per thread = slab / 4
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((nj + slab - 1) / slab), (unsigned)period);
+  DISPATCH(dtype, k_colsum, <<<grid, dim3(256), 0, (hipStream_t)stream>>>((const char*)x, out, rows, cols, period, slab));
   return launch_status();
 }
 

@@ -30,6 +30,21 @@ namespace {
 
 constexpr int BM = 128, BN = 128, KCH = 8;  // KCH chunks of 16 B per K-tile row
 
+// n / d for 0 <= n < 2^31 with a host-precomputed multiplier (round-up method): q = (umulhi(n, mul) + n) >> shr
+struct FastDiv {
+  unsigned mul, shr, d;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.shr = s;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.shr; }
+
 struct ConvArgs {
   const char* x;
   const char* w;
@@ -42,6 +57,7 @@ struct ConvArgs {
   int ldy, ldr, ldm;
   int relu, out_f32, pool;
   int M, Kc, cpp;  // rows, total K chunks, chunks per pixel
+  FastDiv dWo, dHo, dcpp, dKW;
 };
 
 template <typename T> struct Mma;
@@ -102,7 +118,7 @@ template <> __device__ __forceinline__ u32x4 avg4<__bf16>(const u32x4& a, const 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
+__global__ __launch_bounds__(256, 2) void k_conv_fwd_reg(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2][BM * KCH];
   const int t = threadIdx.x;
   const int ntn = (p.Cout + BN - 1) / BN;
@@ -286,6 +302,211 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   }
 }
 
+// LDS-DMA variant (pool == 0): A and B tiles go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
+// instruction = 8 rows x 128 B), double-buffered, with a counted vmcnt so the next tile's 8 DMAs per thread stay in
+// flight across the barrier.  The VGPR -> LDS write path (ds_write_b128 ~13 cycles per wave-instruction) was the
+// bottleneck of the register-staged loop at two blocks per CU.  LDS destination is lane-linear, so the XOR swizzle
+// is applied to the per-lane SOURCE chunk; out-of-image / tail lanes read a 16-byte zero page.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][BM * KCH];   // [buffer][A|B]
+  const int t = threadIdx.x;
+  const int ntn = (p.Cout + BN - 1) / BN;
+  const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int cc = t & 7, rb = t >> 3;
+  const int cl = cc ^ ((rb >> 1) & 7);        // logical K chunk this lane fetches (rows rb+32i share (row>>1)&7)
+
+  // per-thread row geometry, fixed across K-tiles: byte offset of the (ky=kx=0) tap of each of the 4 rows
+  long rowoff[4], wrow[4];
+  int iy0[4], ix0[4];
+  bool vm[4], vn[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + rb + 32 * i;
+    vm[i] = m < p.M;
+    unsigned mm = vm[i] ? m : 0;
+    unsigned tq = fdiv(mm, p.dWo), ox = mm - tq * p.Wo;
+    unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
+    iy0[i] = (int)oy * p.stride - p.pad;
+    ix0[i] = (int)ox * p.stride - p.pad;
+    rowoff[i] = ((((long)img * p.Hi + iy0[i]) * p.Wi + ix0[i]) * p.cpp) * 16;
+    int n = n0 + rb + 32 * i;
+    vn[i] = n < p.Cout;
+    wrow[i] = (long)(vn[i] ? n : 0) * p.Kc * 16;
+  }
+  const int nkt = (p.Kc + KCH - 1) / KCH;
+  const char* zp = (const char*)g_zero_page;
+  const bool taps = !(p.KH == 1 && p.KW == 1 && p.pad == 0);   // 1x1 / linear: every tap is inside the image
+  // running K position of this lane's logical chunk: kc -> (ky, kx, coff); advanced by KCH per tile without divisions
+  int kc = cl;
+  int pp0 = (int)fdiv((unsigned)kc, p.dcpp);
+  int coff = kc - pp0 * p.cpp;
+  int ky = (int)fdiv((unsigned)pp0, p.dKW), kx = pp0 - ky * p.KW;
+
+  auto stage = [&](int buf) {
+    const bool vk = kc < p.Kc;
+    const int delta = ((ky * p.Wi + kx) * p.cpp + coff) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = vk && vm[i];
+      if (taps) {
+        int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+      }
+      const char* src = ok ? p.x + rowoff[i] + delta : zp;
+      glds16(src, &lds[buf][0][(8 * (t >> 6) + 32 * i) * KCH]);      // wave-uniform base; lane l lands at +16*l
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* src = (vk && vn[i]) ? p.w + wrow[i] + (long)kc * 16 : zp;
+      glds16(src, &lds[buf][1][(8 * (t >> 6) + 32 * i) * KCH]);
+    }
+    kc += KCH;
+    coff += KCH;
+    while (coff >= p.cpp) {
+      coff -= p.cpp;
+      if (++kx == p.KW) { kx = 0; ++ky; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lane = t & 63, wv = t >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  stage(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) {
+      stage(cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this tile's 8 DMAs done; the next tile's 8 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ks = 0; ks < KCH / 2; ++ks) {
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = lds[cur][0][swz(wm * 64 + i * 32 + r, 2 * ks + h)];
+        fb[i] = lds[cur][1][swz(wn * 64 + i * 32 + r, 2 * ks + h)];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) Mma<T>::step(acc[a][b], fa[a], fb[b]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // everyone is done reading buffer `cur`
+  }
+
+  // ---------------------------------------------------------------------------------------------
+  // epilogue.  C/D map of the 32x32 MFMA: col = lane&31 (n), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (m).
+  // Vector path (all leading dims multiples of 8): each wave transposes its accumulators through LDS
+  // (32 rows x 64 cols f32 per pass, 32-byte column groups XOR-swizzled by row) so that every lane owns
+  // 8 consecutive channels of one pixel: residual / mask are read and y is written 16-32 B per lane,
+  // whole 128-B lines per 8 lanes -- the scalar path issued 64 two-byte stores per lane instead.
+  const bool vec_ok = (p.Cout % 8 == 0) && (p.ldy % 8 == 0) && (!p.residual || p.ldr % 8 == 0) && (!p.relu_mask || p.ldm % 8 == 0);
+  if (vec_ok) {
+    float* ep = (float*)&lds[0][0][0] + wv * 2048;      // 8 KB per wave; the K-loop's last barrier already passed
+    const int cg = lane & 7, rr = lane >> 3;
+    const int n = n0 + wn * 64 + cg * 8;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = (p.scale && n + j < p.Cout) ? p.scale[n + j] : 1.f;
+      bi[j] = (p.bias && n + j < p.Cout) ? p.bias[n + j] : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          int row = (g & 3) + 8 * (g >> 2) + 4 * h, col = b * 32 + r;
+          ep[row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7))] = acc[a][b][g];
+        }
+      __syncthreads();
+      if (n < p.Cout) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int row = rr + 8 * i;
+          int m = m0 + wm * 64 + a * 32 + row;
+          if (m >= p.M) continue;
+          const f32x4* src = (const f32x4*)(ep + row * 64 + ((cg ^ (row & 7)) << 3));
+          f32x4 v0 = src[0], v1 = src[1];
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+          if (p.residual) {
+            float rv[8];
+            load8<T>(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES, rv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rv[j];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (p.relu_mask) {
+            float mv[8];
+            load8<T>(p.relu_mask + ((long)m * p.ldm + n) * Mma<T>::ES, mv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
+          }
+          if (p.out_f32 || Mma<T>::ES == 4) {
+            f32x4* dst = (f32x4*)(p.y + ((long)m * p.ldy + n) * 4);
+            f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+            dst[0] = o0; dst[1] = o1;
+          } else {
+            u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+            *(u32x4*)(p.y + ((long)m * p.ldy + n) * 2) = o;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    int n = n0 + wn * 64 + b * 32 + r;
+    if (n >= p.Cout) continue;
+    float sc = p.scale ? p.scale[n] : 1.f;
+    float bi = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        int m = m0 + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[a][b][g] * sc + bi;
+        if (p.residual) v += Mma<T>::load(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES);
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu_mask && !(Mma<T>::load(p.relu_mask + ((long)m * p.ldm + n) * Mma<T>::ES) > 0.f)) v = 0.f;
+        if (p.out_f32) *(float*)(p.y + ((long)m * p.ldy + n) * 4) = v;
+        else Mma<T>::store(p.y + ((long)m * p.ldy + n) * Mma<T>::ES, v);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad:  dW[n][k] += scale[n] * sum_m dY[m][n] * A[m][k]
 // ------------------------------------------------------------------------------------------------
@@ -297,6 +518,7 @@ struct WgradArgs {
   int Nimg, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ldd, pool;
   int M, Kc, cpp, K, ncc;  // ncc = chunks per dY row that exist (Cout*ES/16)
   int mtiles_per_split;
+  FastDiv dWo, dHo;
 };
 
 constexpr int WM = 64;                 // m rows per reduction tile
@@ -370,9 +592,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
     for (int i = 0; i < 4; ++i) {
       int m = mt * WM + rb + 16 * i;
       bool vmm = m < p.M;
-      int mm = vmm ? m : 0;
-      int ox = mm % p.Wo, tq = mm / p.Wo;
-      int oy = tq % p.Ho, img = tq / p.Ho;
+      unsigned mm = vmm ? m : 0;
+      unsigned tq = fdiv(mm, p.dWo);
+      int ox = (int)(mm - tq * p.Wo);
+      unsigned img = fdiv(tq, p.dHo);
+      int oy = (int)(tq - img * p.Ho);
       if (!p.pool) {
         int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
         bool ok = vmm && vk && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
@@ -469,7 +693,8 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   long grid = (long)ntn * ntm;
   if (grid <= 0) return CDDMSL_OK;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
-  hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  if (a.pool) hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
   return launch_status();
 }
 
@@ -495,6 +720,8 @@ extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const floa
   long M = (long)Nimg * a.Ho * a.Wo;
   if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
   a.M = (int)M; a.cpp = Cin * es / 16; a.Kc = KH * KW * a.cpp;
+  a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
+  a.dcpp = make_fastdiv((unsigned)a.cpp); a.dKW = make_fastdiv((unsigned)KW);
   if (a.M == 0) return CDDMSL_OK;
   return dtype == 0 ? conv_fwd_launch<__bf16>(a, (hipStream_t)stream) : conv_fwd_launch<float>(a, (hipStream_t)stream);
 }
@@ -517,6 +744,7 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   long M = (long)Nimg * a.Ho * a.Wo;
   if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
   a.M = (int)M; a.cpp = Cin * es / 16; a.Kc = KH * KW * a.cpp; a.K = KH * KW * Cin; a.ncc = Cout * es / 16;
+  a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
   if (a.M == 0) return CDDMSL_OK;
   int cols = 256 / es;
   long tiles = (long)((Cout + cols - 1) / cols) * ((a.K + cols - 1) / cols);
