@@ -75,7 +75,9 @@ def main():
     from cddmsl_amd import engine, hip
     rank, world = engine.init_distributed()
     assert world == max(args.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    # CDDMSL_SHARE_GPU=1 (rehearsal only): all ranks on device 0 with the gloo backend, to exercise the N>1 code path
+    # on a one-GPU box; RCCL itself needs one device per rank.
+    dev = torch.device("cuda", 0 if os.environ.get("CDDMSL_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
     cfg = make_cfg(args.dtype)
     cfg.MODEL.DEVICE = str(dev)

@@ -96,6 +96,13 @@ template <> __device__ __forceinline__ void load8<float>(const char* p, float* f
   f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
 }
 
+// XCD-aware tile order (8 XCDs, blocks dealt round-robin): give each XCD a contiguous run of logical tiles so the
+// tiles that share an A row-panel / weight panel hit the same 4 MiB L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, rem = nblk & 7, x = bid & 7, j = bid >> 3;
+  return (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+}
+
 __device__ __forceinline__ int swz(int row, int chunk) { return row * KCH + (chunk ^ ((row >> 1) & 7)); }
 
 // average of 4 packed chunks (2x2 avg-pool fused into the A loader)
@@ -319,7 +326,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][BM * KCH];   // [buffer][A|B]
   const int t = threadIdx.x;
   const int ntn = (p.Cout + BN - 1) / BN;
-  const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = lbid % ntn, tile_m = lbid / ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int cc = t & 7, rb = t >> 3;
   const int cl = cc ^ ((rb >> 1) & 7);        // logical K chunk this lane fetches (rows rb+32i share (row>>1)&7)
@@ -399,18 +407,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
+    // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (two named register sets, static indices)
+    u32x4 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[0][i] = lds[cur][0][swz(wm * 64 + i * 32 + r, h)];
+      fb[0][i] = lds[cur][1][swz(wn * 64 + i * 32 + r, h)];
+    }
 #pragma unroll
     for (int ks = 0; ks < KCH / 2; ++ks) {
-      u32x4 fa[2], fb[2];
+      if (ks + 1 < KCH / 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = lds[cur][0][swz(wm * 64 + i * 32 + r, 2 * ks + h)];
-        fb[i] = lds[cur][1][swz(wn * 64 + i * 32 + r, 2 * ks + h)];
+        for (int i = 0; i < 2; ++i) {
+          fa[(ks + 1) & 1][i] = lds[cur][0][swz(wm * 64 + i * 32 + r, 2 * (ks + 1) + h)];
+          fb[(ks + 1) & 1][i] = lds[cur][1][swz(wn * 64 + i * 32 + r, 2 * (ks + 1) + h)];
+        }
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) Mma<T>::step(acc[a][b], fa[a], fb[b]);
+        for (int b = 0; b < 2; ++b) Mma<T>::step(acc[a][b], fa[ks & 1][a], fb[ks & 1][b]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                          // everyone is done reading buffer `cur`
@@ -566,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2][WM * WROW];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int ntn = (p.Cout + COLS - 1) / COLS, ntk = (p.K + COLS - 1) / COLS;
-  int bid = blockIdx.x;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_k = bid % ntk; bid /= ntk;
   const int tile_n = bid % ntn; bid /= ntn;
   const int split = bid;

@@ -31,8 +31,9 @@ def init_distributed(backend=None):
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+            torch.cuda.set_device(0 if os.environ.get("CDDMSL_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0")))
+        backend = backend or os.environ.get("CDDMSL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend)
     return get_rank(), get_world_size()
 
 
