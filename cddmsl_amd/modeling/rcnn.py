@@ -96,13 +96,13 @@ class GeneralizedRCNN(nn.Module):
         return hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype), sizes
 
     def preprocess_image_train(self, batched_inputs):
-        """rcnn.py:161-179 -> two NHWC [N,224,224,Cp] tensors (source, target)"""
-        outs = []
-        for key in ("image", "image_trgt"):
-            imgs = self._images(batched_inputs, key)
-            Hp, Wp = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
-            outs.append(hip.preprocess224(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype))
-        return outs
+        """rcnn.py:161-179 -> NHWC [2N,224,224,Cp]: rows [0,N) = source images, [N,2N) = target images.
+        (The reference pads source and target batches separately; every sample pair shares one size, so the padded
+        sizes coincide -- asserted.)"""
+        src, tgt = self._images(batched_inputs, "image"), self._images(batched_inputs, "image_trgt")
+        Hp, Wp = max(i.shape[-2] for i in src), max(i.shape[-1] for i in src)
+        assert (Hp, Wp) == (max(i.shape[-2] for i in tgt), max(i.shape[-1] for i in tgt))
+        return hip.preprocess224(src + tgt, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype)
 
     # ------------------------------------------------------------------ pieces
     def project(self, x):
@@ -116,41 +116,47 @@ class GeneralizedRCNN(nn.Module):
         feats = bb.forward_nhwc(img_nhwc)
         return bb.attnpool(to_nchw(feats["res5"]))
 
-    def v2l_contrastive(self, images_src, images_target, clipcap_model, KD_regularization=True):
-        """rcnn.py:255-319"""
-        ft = self.project(v2l(self._encode(self.backbone, images_target), clipcap_model))
-        fs = v2l(self._encode(self.backbone, images_src), clipcap_model)
+    def v2l_contrastive(self, images_both, clipcap_model, KD_regularization=True):
+        """rcnn.py:255-319.  ``images_both`` = [source; target] stacked on the batch axis: the student runs ONCE over 2N
+        images (per-sample results are identical to two passes; half the launches)."""
+        n = images_both.shape[0] // 2
+        f = v2l(self._encode(self.backbone, images_both), clipcap_model)     # [2N, 768]
+        fs, ft = f[:n], f[n:]
         kd_loss = None
         if KD_regularization:
             with torch.no_grad():
-                teacher = v2l(self._encode(self.offline_backbone, images_src), clipcap_model)
+                teacher = v2l(self._encode(self.offline_backbone, images_both[:n]), clipcap_model)
             kd_loss = torch.nn.functional.l1_loss(teacher.detach(), fs)
-        fs = self.project(fs)
-        ft, fs = gather_cat(ft), gather_cat(fs)
+        p = self.project(f)
+        fs, ft = gather_cat(p[:n].contiguous()), gather_cat(p[n:].contiguous())
         return layers.contrastive_loss(ft, fs), kd_loss
 
     # ------------------------------------------------------------------ forward
     def forward(self, batched_inputs: List[Dict], clipcap_model=None, branch="supervised", KD_regularization=True):
         assert self.training, "inference is a 'next' row (SURVEY.md 8(f))"
         if branch == "caption_consistency":                     # rcnn.py:413-421
-            src, tgt = self.preprocess_image_train(batched_inputs)
-            cont, kd = self.v2l_contrastive(src, tgt, clipcap_model, KD_regularization)
+            both = self.preprocess_image_train(batched_inputs)
+            cont, kd = self.v2l_contrastive(both, clipcap_model, KD_regularization)
             return {"cont_loss": cont, "kd_loss": kd} if kd is not None else {"cont_loss": cont}
         if branch == "caption_consistency_regionLevel":         # rcnn.py:422-470
-            src, sizes = self.preprocess_image(batched_inputs, "image")
-            tgt, _ = self.preprocess_image(batched_inputs, "image_trgt")
-            fs = self.backbone.forward_nhwc(src, want_res5=False)["res4"]
-            ft = self.backbone.forward_nhwc(tgt, want_res5=False)["res4"]
+            # source and target images stacked on the batch axis: one backbone pass over 2N images, one RoI pass over
+            # 2x16N regions (identical per-sample results, half the kernel launches)
+            n = len(batched_inputs)
+            imgs = self._images(batched_inputs, "image") + self._images(batched_inputs, "image_trgt")
+            sizes = [tuple(i.shape[-2:]) for i in imgs[:n]]
+            assert sizes == [tuple(i.shape[-2:]) for i in imgs[n:]], "a sample and its domain twin share one geometry"
+            Hp, Wp = max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes)
+            both = hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype)
+            f = self.backbone.forward_nhwc(both, want_res5=False)["res4"]
             gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]
             with torch.no_grad():
-                props, _ = self.proposal_generator.forward_nhwc(sizes, fs.detach(), gts)
+                props, _ = self.proposal_generator.forward_nhwc(sizes, f[:n].detach(), gts)
                 sel = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image].to(self.device) for p in props]
                 props = [p[s] for p, s in zip(props, sel)]
-            rs, rt = self.roi_heads.forward_get_features({"res4": to_nchw(fs)}, {"res4": to_nchw(ft)}, props, targets=gts,
-                                                         res5=self.backbone.layer4, attnpool=self.backbone.attnpool)
-            es = self.project(v2l(rs, clipcap_model))
-            et = self.project(v2l(rt, clipcap_model))
-            return layers.contrastive_loss(gather_cat(es), gather_cat(et))
+            rs, rt = self.roi_heads.forward_get_features_paired(f, n, props, self.backbone.layer4, self.backbone.attnpool)
+            e = self.project(v2l(torch.cat([rs, rt]), clipcap_model))
+            k = rs.shape[0]
+            return layers.contrastive_loss(gather_cat(e[:k].contiguous()), gather_cat(e[k:].contiguous()))
         # supervised: rcnn.py:592-623
         images, sizes = self.preprocess_image(batched_inputs, "image")
         gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]

@@ -16,7 +16,7 @@ from .. import hip, layers
 from ..registry import ROI_HEADS_REGISTRY
 from ..structures import Boxes, Instances, ShapeSpec, as_instances
 from .backbone import to_nhwc, to_nchw
-from .rpn import get_deltas, subsample_labels
+from .rpn import get_deltas, subsample_labels_batched
 
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))  # proposal_utils.py:183
 
@@ -157,6 +157,7 @@ class CLIPRes5ROIHeads(nn.Module):
     def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]):
         """roi_heads.py:236-319 (+ add_ground_truth_to_proposals proposal_utils.py:133-200, _sample_proposals :184-234)"""
         out, nfg, nbg = [], [], []
+        staged = []
         for prop, tgt in zip(proposals, targets):
             gtb = tgt.gt_boxes.tensor.float().contiguous()
             gtc = tgt.gt_classes
@@ -172,7 +173,10 @@ class CLIPRes5ROIHeads(nn.Module):
                 cls[mlab == -1] = -1
             else:
                 cls = torch.zeros_like(midx) + self.num_classes
-            fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, self.num_classes, self.sample_generator)
+            staged.append((prop, gtb, gtc, boxes, logits, midx, cls))
+        picks = subsample_labels_batched([st[6] for st in staged], self.batch_size_per_image, self.positive_fraction,
+                                         self.num_classes, self.sample_generator)
+        for (prop, gtb, gtc, boxes, logits, midx, cls), (fg, bg) in zip(staged, picks):
             sidx = torch.cat([fg, bg], dim=0)
             inst = Instances(prop.image_size)
             inst.proposal_boxes, inst.objectness_logits, inst.gt_classes = Boxes(boxes[sidx]), logits[sidx], cls[sidx]
@@ -197,6 +201,15 @@ class CLIPRes5ROIHeads(nn.Module):
         fs = self._shared_roi_transform(to_nhwc(features_src[self.in_features[0]]), boxes, res5)
         ft = self._shared_roi_transform(to_nhwc(features_trgt[self.in_features[0]]), boxes, res5)
         return attnpool(to_nchw(fs)), attnpool(to_nchw(ft))
+
+    def forward_get_features_paired(self, feat_cat_nhwc, num_images, proposals, res5, attnpool):
+        """Same result as ``forward_get_features`` when source and target maps are stacked along the batch axis
+        (images [0,B) = source, [B,2B) = target): ONE RoIAlign / layer4 / attention-pool pass over 2K regions."""
+        boxes = [p.proposal_boxes for p in proposals]
+        x = self._shared_roi_transform(feat_cat_nhwc, boxes + boxes, res5)
+        att = attnpool(to_nchw(x))
+        k = att.shape[0] // 2
+        return att[:k], att[k:]
 
     def forward(self, images, features, proposals, targets=None, res5=None, attnpool=None):
         """clip_roi_heads.py:134-175 (training)."""

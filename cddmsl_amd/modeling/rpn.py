@@ -44,6 +44,40 @@ def subsample_labels(labels, num_samples, positive_fraction, bg_label, gen):
     return positive[perm1], negative[perm2]
 
 
+def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_label, gen):
+    """``subsample_labels`` for a list of per-image label vectors with TWO device->host syncs in total instead of two per
+    image: one nonzero over the concatenated positives, one over the negatives; the per-image permutations are then drawn
+    on the host in the reference's order (image by image: positives, negatives -- sampling.py:47-48)."""
+    lens = [int(l.numel()) for l in label_list]
+    cat = torch.cat(label_list)
+    pos_all = torch.nonzero((cat != -1) & (cat != bg_label), as_tuple=True)[0]
+    neg_all = torch.nonzero(cat == bg_label, as_tuple=True)[0]
+    offs = torch.tensor([0] + lens).cumsum(0)
+    bounds = offs.to(cat.device)
+    # per-image counts from the sorted index lists (one small D2H copy)
+    cnt = torch.stack([torch.searchsorted(pos_all, bounds), torch.searchsorted(neg_all, bounds)]).cpu()
+    out = []
+    for i in range(len(label_list)):
+        p0, p1 = int(cnt[0, i]), int(cnt[0, i + 1])
+        n0, n1 = int(cnt[1, i]), int(cnt[1, i + 1])
+        npos, nneg = p1 - p0, n1 - n0
+        num_pos = min(npos, int(num_samples * positive_fraction))
+        num_neg = min(nneg, num_samples - num_pos)
+        perm1 = torch.randperm(npos, generator=gen)[:num_pos]
+        perm2 = torch.randperm(nneg, generator=gen)[:num_neg]
+        out.append((perm1 + p0, perm2 + n0, int(offs[i])))
+    # one H2D copy for all index lists
+    sel_pos = torch.cat([o[0] for o in out]).to(cat.device)
+    sel_neg = torch.cat([o[1] for o in out]).to(cat.device)
+    pos_idx, neg_idx = pos_all[sel_pos], neg_all[sel_neg]
+    res, a, b = [], 0, 0
+    for (p, n, off) in out:
+        res.append((pos_idx[a:a + len(p)] - off, neg_idx[b:b + len(n)] - off))
+        a += len(p)
+        b += len(n)
+    return res
+
+
 # ------------------------------------------------------------------------------------------------ anchors
 @ANCHOR_GENERATOR_REGISTRY.register()
 class DefaultAnchorGenerator(nn.Module):
@@ -156,12 +190,13 @@ class RPN(nn.Module):
         for gi in gt_instances:
             gtb = gi.gt_boxes.tensor.float().contiguous()
             idx, lab = hip.iou_match(gtb, anchors, self.iou_thresholds, self.iou_labels, True)
-            pos, neg = subsample_labels(lab, self.batch_size_per_image, self.positive_fraction, 0, self.sample_generator)
+            labels.append(lab)
+            matched.append(torch.zeros_like(anchors) if len(gtb) == 0 else gtb[idx])
+        picks = subsample_labels_batched(labels, self.batch_size_per_image, self.positive_fraction, 0, self.sample_generator)
+        for lab, (pos, neg) in zip(labels, picks):
             lab.fill_(-1)
             lab[pos] = 1
             lab[neg] = 0
-            labels.append(lab)
-            matched.append(torch.zeros_like(anchors) if len(gtb) == 0 else gtb[idx])
         return labels, matched
 
     def losses(self, anchors, logits, labels, deltas, matched):
