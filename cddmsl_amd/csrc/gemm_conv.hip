@@ -325,6 +325,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][BM * KCH];   // [buffer][A|B]
   const int t = threadIdx.x;
+  const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);     // wave index in an SGPR: LDS-DMA bases become scalar
   const int ntn = (p.Cout + BN - 1) / BN;
   const int lbid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = lbid % ntn, tile_m = lbid / ntn;
@@ -359,7 +360,56 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   int coff = kc - pp0 * p.cpp;
   int ky = (int)fdiv((unsigned)pp0, p.dKW), kx = pp0 - ky * p.KW;
 
+  // Fast path (cpp % 8 == 0, i.e. a K-tile never straddles two filter taps -- every layer past the stem): per-row source
+  // pointers are kept in registers and advanced by 128 B per tile (2 VALU each); tap validity / base addresses are
+  // recomputed only when the (wave-uniform) tap changes.  The general path recomputes everything per tile.
+  const bool fast = (p.cpp & 7) == 0;
+  const char* pa[4];
+  const char* pb[4];
+  int inca[4], incb[4];
+  int tiles_left_in_tap = 0;                    // K-tiles before (ky,kx) advances (fast path)
+  auto retap = [&]() {                          // (re)build the A pointers for the current (ky, kx, coff)
+    const int delta = ((ky * p.Wi + kx) * p.cpp + coff) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = vm[i];
+      if (taps) {
+        int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
+      }
+      pa[i] = ok ? p.x + rowoff[i] + delta : zp;
+      inca[i] = ok ? KCH * 16 : 0;
+    }
+  };
+  if (fast) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pb[i] = vn[i] ? p.w + wrow[i] + (long)kc * 16 : zp;
+      incb[i] = vn[i] ? KCH * 16 : 0;
+    }
+    retap();
+    tiles_left_in_tap = p.cpp >> 3;
+  }
+
   auto stage = [&](int buf) {
+    if (fast) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16(pa[i], &lds[buf][0][(8 * wvu + 32 * i) * KCH]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) glds16(pb[i], &lds[buf][1][(8 * wvu + 32 * i) * KCH]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pb[i] += incb[i];
+      if (--tiles_left_in_tap == 0) {          // wave-uniform: next tile starts a new filter tap
+        tiles_left_in_tap = p.cpp >> 3;
+        coff = cl;
+        if (++kx == p.KW) { kx = 0; ++ky; }
+        retap();
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[i] += inca[i];
+      }
+      return;
+    }
     const bool vk = kc < p.Kc;
     const int delta = ((ky * p.Wi + kx) * p.cpp + coff) * 16;
 #pragma unroll
@@ -370,12 +420,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
         ok = ok && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi;
       }
       const char* src = ok ? p.x + rowoff[i] + delta : zp;
-      glds16(src, &lds[buf][0][(8 * (t >> 6) + 32 * i) * KCH]);      // wave-uniform base; lane l lands at +16*l
+      glds16(src, &lds[buf][0][(8 * wvu + 32 * i) * KCH]);      // wave-uniform base; lane l lands at +16*l
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const char* src = (vk && vn[i]) ? p.w + wrow[i] + (long)kc * 16 : zp;
-      glds16(src, &lds[buf][1][(8 * (t >> 6) + 32 * i) * KCH]);
+      glds16(src, &lds[buf][1][(8 * wvu + 32 * i) * KCH]);
     }
     kc += KCH;
     coff += KCH;

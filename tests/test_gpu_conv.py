@@ -94,7 +94,7 @@ def test_conv_pool_fused(dtype, tol):
 def test_linear_tails():
     """M, N, K tails (not multiples of the 128x128x64 tile) incl. f32 output from bf16 inputs."""
     from cddmsl_amd import hip
-    for M, N, K in [(1, 21, 1024), (130, 75, 1032), (257, 129, 8)]:
+    for M, N, K in [(1, 21, 1024), (130, 75, 1032), (257, 129, 8), (700, 264, 200)]:
         x = _rand((M, K), 21)
         w = _rand((N, K), 22) * K ** -0.5
         b = _rand((N,), 23)
