@@ -734,6 +734,197 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(WgradArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// wgrad, LDS-DMA variant for stride-1 "same" convolutions (1x1/pad 0 and 3x3/pad 1: every trainable layer).
+// Output pixel index == input pixel index, so both operands are walked with pointer increments (64 rows per tile);
+// tiles go global -> LDS by global_load_lds (no VGPR -> LDS write pass, the limiter of the register-staged kernel
+// at two blocks per CU), double-buffered with a counted vmcnt.  LDS rows are plain 256 B; the 16-byte chunk index is
+// XOR-swizzled by f(row) = ((row&3)<<2) | ((row>>2)&3) -- applied to the SOURCE chunk a lane fetches and to the
+// transposed reads -- which keeps ds_read_b64_tr_b16 conflict-free without row padding (padding is impossible with
+// lane-linear DMA writes).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fsw(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// Fragment addressing is split into a per-lane part computed ONCE (fsw of rows ms + 8hh + q does not depend on the
+// 16-row step ms, since ms % 16 == 0) and a compile-time row offset ms * 256 that folds into the DS immediate.
+template <typename T> struct TrFragS;
+template <> struct TrFragS<__bf16> {
+  struct Off { int o0, o1; };
+  __device__ static __forceinline__ Off prep(int col0, int lane) {
+    int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    int hh = g >> 1;
+    int ch = ((col0 + 16 * (g & 1)) >> 3) + (pp >> 1);       // logical 16-byte chunk of columns 4pp..4pp+3
+    int r0 = 8 * hh + q, r1 = r0 + 4;
+    Off o;
+    o.o0 = r0 * 256 + 16 * (ch ^ fsw(r0)) + 8 * (pp & 1);
+    o.o1 = r1 * 256 + 16 * (ch ^ fsw(r1)) + 8 * (pp & 1);
+    return o;
+  }
+  // Inline asm on purpose: through the builtin, hipcc treats the transposed read as "may alias the in-flight LDS-DMA"
+  // and drains vmcnt(0) before it (no overlap with the next tile's DMA).  The asm reads are ordered by the caller's
+  // counted vmcnt + barrier before, and by an explicit lgkmcnt(0) + sched_barrier after (tr_wait()).
+  __device__ static __forceinline__ u32x4 read(const u32x4* base, int ms, const Off& o) {
+    const unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)((const char*)base) + ms * 256;
+    u32x2 p0, p1;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(p0) : "v"(a + o.o0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(p1) : "v"(a + o.o1));
+    u32x4 r = {p0[0], p0[1], p1[0], p1[1]};
+    return r;
+  }
+  static constexpr int MSTEP = 16;
+};
+template <> struct TrFragS<float> {
+  struct Off { int o[4]; };
+  __device__ static __forceinline__ Off prep(int col0, int lane) {
+    int r = lane & 31, hh = lane >> 5;
+    int byte = (col0 + r) * 4;
+    Off o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int row = 4 * hh + j;                                  // + ms (multiple of 8): fsw(row + 8k) flips bit 1 of (row>>2)&3
+      o.o[j] = row * 256 + (byte & 15) + 16 * (byte >> 4);   // swizzle applied in read (depends on ms & 8)
+    }
+    return o;
+  }
+  __device__ static __forceinline__ u32x4 read(const u32x4* base, int ms, const Off& o) {
+    const char* b = (const char*)base;
+    u32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int off = o.o[j] + ms * 256;
+      int row = off >> 8, ch = (off >> 4) & 15;
+      v[j] = *(const unsigned int*)(b + (off & ~0xf0) + 16 * (ch ^ fsw(row)));
+    }
+    return v;
+  }
+  static constexpr int MSTEP = 8;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_dma(WgradArgs p) {
+  constexpr int ES = Mma<T>::ES;
+  constexpr int COLS = 256 / ES;
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][WM * 16];   // [buffer][dY | X][64 rows x 16 chunks]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ntn = (p.Cout + COLS - 1) / COLS, ntk = (p.K + COLS - 1) / COLS;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_k = bid % ntk; bid /= ntk;
+  const int tile_n = bid % ntn; bid /= ntn;
+  const int split = bid;
+  const int n0 = tile_n * COLS, k0 = tile_k * COLS;
+  const int mt0 = split * p.mtiles_per_split;
+  const int total_mt = (p.M + WM - 1) / WM;
+  const int mt1 = min(mt0 + p.mtiles_per_split, total_mt);
+
+  const int cc = t & 15, rb = t >> 4;          // physical chunk / row of this lane's DMA slots (rows rb + 16 i)
+  const int cl = cc ^ fsw(rb);                 // logical chunk it fetches (fsw(rb + 16 i) == fsw(rb))
+  const int kc = k0 * ES / 16 + cl;
+  const bool vk = kc < p.Kc;
+  const int pp = vk ? kc / p.cpp : 0, coff = vk ? kc - pp * p.cpp : 0;
+  const int ky = pp / p.KW, kx = pp - ky * p.KW;
+  const int nc = n0 * ES / 16 + cl;
+  const bool vn = nc < p.ncc;
+  const bool taps = !(p.KH == 1 && p.KW == 1);
+  const char* zp = (const char*)g_zero_page;
+
+  int m[4];
+  const char* pd[4];
+  const char* px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    m[i] = mt0 * WM + rb + 16 * i;
+    pd[i] = p.dy + ((long)m[i] * p.ldd) * ES + (long)nc * 16;
+    px[i] = p.x + (((long)m[i] + (long)(ky - p.pad) * p.Wi + (kx - p.pad)) * p.cpp + coff) * 16;
+  }
+  const long dstep = (long)WM * p.ldd * ES, xstep = (long)WM * p.cpp * 16;
+
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool vmm = m[i] < p.M;
+      glds16((vmm && vn) ? pd[i] : zp, &lds[buf][0][(4 * wvu + 16 * i) * 16]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bool ok = (m[i] < p.M) & vk;
+      if (taps) {                                  // branch-free: every lane does the (cheap) divisions
+        unsigned mm = min((unsigned)m[i], (unsigned)(p.M - 1));
+        unsigned tq = fdiv(mm, p.dWo);
+        unsigned ox = mm - tq * p.Wo;
+        unsigned oy = tq - fdiv(tq, p.dHo) * p.Ho;
+        ok = ok & ((unsigned)((int)oy - p.pad + ky) < (unsigned)p.Hi) & ((unsigned)((int)ox - p.pad + kx) < (unsigned)p.Wi);
+      }
+      glds16(ok ? px[i] : zp, &lds[buf][1][(4 * wvu + 16 * i) * 16]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { m[i] += WM; pd[i] += dstep; px[i] += xstep; }
+  };
+
+  constexpr int WT = COLS / 2;
+  constexpr int NT = WT / 32;
+  const int wn = wv >> 1, wk = wv & 1;
+  f32x16 acc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  typename TrFragS<T>::Off offa[NT], offb[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    offa[i] = TrFragS<T>::prep(wn * WT + i * 32, lane);
+    offb[i] = TrFragS<T>::prep(wk * WT + i * 32, lane);
+  }
+
+  if (mt0 < mt1) stage(0);
+  for (int mt = mt0; mt < mt1; ++mt) {
+    const int cur = (mt - mt0) & 1;
+    if (mt + 1 < mt1) {
+      stage(cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ms = 0; ms < WM; ms += TrFragS<T>::MSTEP) {
+      u32x4 fa[NT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        fa[i] = TrFragS<T>::read(lds[cur][0], ms, offa[i]);
+        fb[i] = TrFragS<T>::read(lds[cur][1], ms, offb[i]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // asm reads are invisible to hipcc's own waitcnt pass
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) Mma<T>::step(acc[a][b], fa[a], fb[b]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      int k = k0 + wk * WT + b * 32 + r;
+      if (k >= p.K) continue;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        int n = n0 + wn * WT + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (n >= p.Cout) continue;
+        float v = acc[a][b][g] * (p.scale ? p.scale[n] : 1.f);
+        atomicAdd(p.dw + (long)n * p.K + k, v);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight_prep: f32 master [Cout][KH][KW][Cin] -> T forward weights (same layout) and T dgrad weights
 // Wd[cin][KH-1-ky][KW-1-kx][cout] = W[cout][ky][kx][cin] * scale[cout]
 // ------------------------------------------------------------------------------------------------
@@ -824,8 +1015,14 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   splits = (total_mt + a.mtiles_per_split - 1) / a.mtiles_per_split;
   long grid = tiles * splits;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
-  if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(k_conv_wgrad<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  const bool same = !pool && stride == 1 && a.Ho == Hi && a.Wo == Wi;   // LDS-DMA kernel: output pixel == input pixel
+  if (same) {
+    if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_conv_wgrad<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+  }
   return launch_status();
 }
 
