@@ -168,3 +168,135 @@ extern "C" int cddmsl_contrastive_bwd(const float* S, const float* rlse, const f
   k_contrastive_grad<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(S, rlse, clse, gloss, dS, n, ld);
   return launch_status();
 }
+
+// ================================================================================================
+// LayerNorm (mapper, clipcap.py:97-100 pre-LN) and the detection losses as fused fp32 kernels
+//   layernorm        nn.LayerNorm(768), eps 1e-5, frozen affine: f32 residual stream in, T (GEMM operand) out
+//   focal CE         FastRCNNOutputLayers.focal_loss  fast_rcnn.py:624-644  mean_i CE_i (1-p_t)^gamma w_i
+//   box L1           box_reg_loss                     fast_rcnn.py:646-689  sum over fg rows / R
+//   BCE-with-logits  RPN.losses                       rpn.py:405-427        sum over sampled anchors
+// ================================================================================================
+namespace {
+
+template <typename T> struct OutT;
+template <> struct OutT<__bf16> { __device__ static __forceinline__ void st(void* p, long i, float v) { ((unsigned short*)p)[i] = f2bf(v); }
+                                  __device__ static __forceinline__ float ld(const void* p, long i) { return bf2f(((const unsigned short*)p)[i]); } };
+template <> struct OutT<float> { __device__ static __forceinline__ void st(void* p, long i, float v) { ((float*)p)[i] = v; }
+                                 __device__ static __forceinline__ float ld(const void* p, long i) { return ((const float*)p)[i]; } };
+
+// one wave per row
+template <typename T>
+__global__ void k_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                long R, int D, float eps) {
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* xr = x + r * D;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) s += xr[d];
+  float mu = wave_sum(s) / (float)D;
+  float v = 0.f;
+  for (int d = lane; d < D; d += 64) { float c = xr[d] - mu; v += c * c; }
+  float rs = rsqrtf(wave_sum(v) / (float)D + eps);
+  for (int d = lane; d < D; d += 64) OutT<T>::st(y, r * D + d, (xr[d] - mu) * rs * gamma[d] + beta[d]);
+  if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma   (affine frozen: no dgamma/dbeta)
+template <typename T>
+__global__ void k_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                float* dx, long R, int D, int accumulate) {
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* xr = x + r * D;
+  float mu = mean[r], rs = rstd[r];
+  float sg = 0.f, sgx = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    float g = OutT<T>::ld(dy, r * D + d) * gamma[d];
+    float xh = (xr[d] - mu) * rs;
+    sg += g; sgx += g * xh;
+  }
+  sg = wave_sum(sg) / (float)D; sgx = wave_sum(sgx) / (float)D;
+  for (int d = lane; d < D; d += 64) {
+    float g = OutT<T>::ld(dy, r * D + d) * gamma[d];
+    float xh = (xr[d] - mu) * rs;
+    float v = rs * (g - sg - xh * sgx);
+    dx[r * D + d] = accumulate ? dx[r * D + d] + v : v;
+  }
+}
+
+// focal-scaled, background-weighted CE over [R][C] logits (C <= 64): one lane per class, 4 rows per block.
+// row_loss[r] = CE * (1-pt)^gamma * w ; dlogits (mean reduction folded in by the caller's upstream gradient).
+__global__ void k_focal_ce_fwd(const float* logits, const long* target, float* row_loss, float* probs, long R, int C,
+                               float gamma, int bg_class, float bg_weight) {
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  float z = lane < C ? logits[r * C + lane] : -INFINITY;
+  float mx = wave_max(z);
+  float e = lane < C ? expf(z - mx) : 0.f;
+  float se = wave_sum(e);
+  float p = e / se;
+  if (lane < C) probs[r * C + lane] = p;
+  int t = (int)target[r];
+  float zt = __shfl(z, t, 64), pt = __shfl(p, t, 64);
+  if (lane == 0) {
+    float ce = (mx + logf(se)) - zt;
+    float w = (t == bg_class) ? bg_weight : 1.f;
+    float mod = gamma > 0.f ? powf(fmaxf(1.f - pt, 0.f), gamma) : 1.f;
+    row_loss[r] = ce * mod * w;
+  }
+}
+// d(row_loss)/d(logit_c) = w * [ mod * (p_c - 1[c==t]) + ce * d(mod)/dz_c ],  d(mod)/dz_c = -gamma (1-pt)^(gamma-1) pt (1[c==t] - p_c)
+__global__ void k_focal_ce_bwd(const float* logits, const long* target, const float* probs, const float* gscale, float* dlogits,
+                               long R, int C, float gamma, int bg_class, float bg_weight) {
+  long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  int t = (int)target[r];
+  float p = lane < C ? probs[r * C + lane] : 0.f;
+  float pt = __shfl(p, t, 64);
+  float w = (t == bg_class) ? bg_weight : 1.f;
+  float one = lane == t ? 1.f : 0.f;
+  float ce = -logf(fmaxf(pt, 1e-38f));
+  float omp = fmaxf(1.f - pt, 0.f);
+  float mod = gamma > 0.f ? powf(omp, gamma) : 1.f;
+  float dmod = (gamma > 0.f && omp > 0.f) ? -gamma * powf(omp, gamma - 1.f) * pt * (one - p) : 0.f;
+  float g = w * (mod * (p - one) + ce * dmod) * gscale[0];
+  if (lane < C) dlogits[r * C + lane] = g;
+}
+
+}  // namespace
+
+extern "C" int cddmsl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                    long R, int D, float eps, int dtype, void* stream) {
+  if (R < 0 || D <= 0 || (dtype != 0 && dtype != 1)) return CDDMSL_ERR_ARG;
+  if (R == 0) return CDDMSL_OK;
+  dim3 grid((unsigned)((R + 3) / 4));
+  if (dtype == 0) k_layernorm_fwd<__bf16><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, gamma, beta, y, mean, rstd, R, D, eps);
+  else k_layernorm_fwd<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, gamma, beta, y, mean, rstd, R, D, eps);
+  return launch_status();
+}
+extern "C" int cddmsl_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                    float* dx, long R, int D, int accumulate, int dtype, void* stream) {
+  if (R < 0 || D <= 0 || (dtype != 0 && dtype != 1)) return CDDMSL_ERR_ARG;
+  if (R == 0) return CDDMSL_OK;
+  dim3 grid((unsigned)((R + 3) / 4));
+  if (dtype == 0) k_layernorm_bwd<__bf16><<<grid, dim3(256), 0, (hipStream_t)stream>>>(dy, x, gamma, mean, rstd, dx, R, D, accumulate);
+  else k_layernorm_bwd<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>(dy, x, gamma, mean, rstd, dx, R, D, accumulate);
+  return launch_status();
+}
+extern "C" int cddmsl_focal_ce_fwd(const float* logits, const long* target, float* row_loss, float* probs, long R, int C,
+                                   float gamma, int bg_class, float bg_weight, void* stream) {
+  if (R < 0 || C <= 0 || C > 64) return CDDMSL_ERR_ARG;
+  if (R == 0) return CDDMSL_OK;
+  k_focal_ce_fwd<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(logits, target, row_loss, probs, R, C, gamma, bg_class, bg_weight);
+  return launch_status();
+}
+extern "C" int cddmsl_focal_ce_bwd(const float* logits, const long* target, const float* probs, const float* gscale,
+                                   float* dlogits, long R, int C, float gamma, int bg_class, float bg_weight, void* stream) {
+  if (R < 0 || C <= 0 || C > 64) return CDDMSL_ERR_ARG;
+  if (R == 0) return CDDMSL_OK;
+  k_focal_ce_bwd<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(logits, target, probs, gscale, dlogits, R, C, gamma, bg_class, bg_weight);
+  return launch_status();
+}

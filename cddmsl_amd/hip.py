@@ -45,6 +45,10 @@ def _L():
         L.cddmsl_l2norm_bwd.argtypes = [vp, vp, vp, vp, c_long, ci, vp]
         L.cddmsl_cosine_logits_fwd.argtypes = [vp] * 4 + [c_long, ci, ci, cf, cf, vp]
         L.cddmsl_cosine_logits_bwd.argtypes = [vp] * 5 + [c_long, ci, ci, cf, ci, vp]
+        L.cddmsl_layernorm_fwd.argtypes = [vp] * 6 + [c_long, ci, cf, ci, vp]
+        L.cddmsl_layernorm_bwd.argtypes = [vp] * 6 + [c_long, ci, ci, ci, vp]
+        L.cddmsl_focal_ce_fwd.argtypes = [vp] * 4 + [c_long, ci, cf, ci, cf, vp]
+        L.cddmsl_focal_ce_bwd.argtypes = [vp] * 5 + [c_long, ci, cf, ci, cf, vp]
         L.cddmsl_contrastive_fwd.argtypes = [vp] * 4 + [ci, ci, vp]
         L.cddmsl_contrastive_bwd.argtypes = [vp] * 5 + [ci, ci, vp]
         _sigs_done = True
@@ -525,3 +529,47 @@ def contrastive_bwd(S, rl, cl, gloss):
     check(_L().cddmsl_contrastive_bwd(ptr(S), ptr(rl), ptr(cl), ptr(gloss.reshape(1).float().contiguous()), ptr(dS), n, n, stream_ptr()),
           "cddmsl_contrastive_bwd")
     return dS
+
+
+@_timed("layernorm")
+def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
+    """x [R,D] f32 -> (y [R,D] out_dtype, mean [R], rstd [R])"""
+    require_cuda(x, gamma, beta)
+    R, D = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty((R, D), device=x.device, dtype=out_dtype)
+    mean = torch.empty(R, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(R, device=x.device, dtype=torch.float32)
+    check(_L().cddmsl_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), R, D, eps, DT[out_dtype], stream_ptr()),
+          "cddmsl_layernorm_fwd")
+    return y, mean, rstd
+
+
+@_timed("layernorm")
+def layernorm_bwd(dy, x, gamma, mean, rstd):
+    require_cuda(dy, x, gamma, mean, rstd)
+    R, D = x.shape
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    check(_L().cddmsl_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), R, D, 0, _dt(dy), stream_ptr()),
+          "cddmsl_layernorm_bwd")
+    return dx
+
+
+def focal_ce_fwd(logits, target, gamma, bg_class, bg_weight):
+    require_cuda(logits, target)
+    R, C = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and target.dtype == torch.int64
+    row = torch.empty(R, device=logits.device, dtype=torch.float32)
+    probs = torch.empty_like(logits)
+    check(_L().cddmsl_focal_ce_fwd(ptr(logits), ptr(target), ptr(row), ptr(probs), R, C, gamma, bg_class, bg_weight, stream_ptr()),
+          "cddmsl_focal_ce_fwd")
+    return row, probs
+
+
+def focal_ce_bwd(logits, target, probs, gscale, gamma, bg_class, bg_weight):
+    require_cuda(logits, target, probs, gscale)
+    d = torch.empty_like(logits)
+    check(_L().cddmsl_focal_ce_bwd(ptr(logits), ptr(target), ptr(probs), ptr(gscale.reshape(1).float().contiguous()), ptr(d), logits.shape[0],
+                                   logits.shape[1], gamma, bg_class, bg_weight, stream_ptr()), "cddmsl_focal_ce_bwd")
+    return d

@@ -409,3 +409,44 @@ class ContrastiveFn(torch.autograd.Function):
 
 def contrastive_loss(a, b):
     return ContrastiveFn.apply(a, b)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """Frozen-affine LayerNorm of the mapper: f32 residual stream in, compute-dtype GEMM operand out (clipcap.py:97-100)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, out_dtype):
+        y, mean, rstd = hip.layernorm_fwd(x.contiguous(), gamma, beta, out_dtype)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        return hip.layernorm_bwd(dy, x.contiguous(), gamma, mean, rstd), None, None, None
+
+
+def layer_norm(x2d, gamma, beta, out_dtype):
+    return LayerNormFn.apply(x2d, gamma.detach(), beta.detach(), out_dtype)
+
+
+class FocalCEFn(torch.autograd.Function):
+    """mean_i[ CE_i * (1 - p_t)^gamma * (bg_weight if target == bg else 1) ]   (fast_rcnn.py:624-644)"""
+
+    @staticmethod
+    def forward(ctx, logits, target, gamma, bg_class, bg_weight):
+        logits = logits.contiguous()
+        row, probs = hip.focal_ce_fwd(logits, target, gamma, bg_class, bg_weight)
+        ctx.save_for_backward(logits, target, probs)
+        ctx.meta = (gamma, bg_class, bg_weight)
+        return row.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, probs = ctx.saved_tensors
+        gamma, bg_class, bg_weight = ctx.meta
+        return hip.focal_ce_bwd(logits, target, probs, g / logits.shape[0], gamma, bg_class, bg_weight), None, None, None, None
+
+
+def focal_cross_entropy(logits, target, gamma, bg_class, bg_weight):
+    return FocalCEFn.apply(logits, target, float(gamma or 0.0), int(bg_class), float(1.0 if bg_weight is None else bg_weight))

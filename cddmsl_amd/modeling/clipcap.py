@@ -3,7 +3,8 @@
 Only ``TransformerMapper`` is built (``ClipCaptionModel.clip_project``, engine/train_loop.py:281-288); GPT-2 is
 never constructed (it is off the hot path and needs a network fetch).  Parameter names match ``clip_project.*``.
 The linears (31 M + 38 M frozen parameters, 3.13 GMAC/sample) run on the HIP MFMA GEMM with input-gradient only;
-LayerNorm / the 80-token softmax are small fp32 elementwise pieces kept on torch ops this round ("next").
+LayerNorm is a fused HIP kernel (f32 residual stream in, GEMM operand out); the 80-token softmax(QK^T)V core is kept on
+torch ops this round ("next").
 """
 import torch
 import torch.nn.functional as F
@@ -77,14 +78,14 @@ class TransformerMapper(nn.Module):
         for lyr in self.transformer.layers:
             a = lyr.attn
             H = a.num_heads
-            y = F.layer_norm(h, (d,), lyr.norm1.weight, lyr.norm1.bias).to(T).view(n * t, d)
+            y = layers.layer_norm(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
             q = a.to_queries(y).view(n, t, H, d // H).permute(0, 2, 1, 3)
             kv = a.to_keys_values(y).view(n, t, 2, H, d // H)
             k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)
             att = torch.softmax((q @ k.transpose(-1, -2)) * a.scale, dim=-1)
             o = (att @ v).permute(0, 2, 1, 3).reshape(n * t, d)
             h = h + a.project(o.to(T)).view(n, t, d)
-            y = F.layer_norm(h, (d,), lyr.norm2.weight, lyr.norm2.bias).to(T).view(n * t, d)
+            y = layers.layer_norm(h.view(n * t, d), lyr.norm2.weight, lyr.norm2.bias, T)
             y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True).to(T))
             h = h + y.view(n, t, d)
         return h[:, self.clip_length:]

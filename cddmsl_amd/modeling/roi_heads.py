@@ -104,16 +104,7 @@ class FastRCNNOutputLayers(nn.Module):
         pboxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
         gboxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
         self._log_stats(scores.detach(), gt_classes)
-        ce = F.cross_entropy(scores, gt_classes, reduction="none")
-        if self.focal_scaled_loss is not None:   # focal_loss :624-644
-            p = F.softmax(scores, dim=-1)
-            pt = p[torch.arange(p.size(0), device=p.device), gt_classes]
-            ce = ce * ((1 - pt) ** self.focal_scaled_loss)
-        if self.bg_cls_loss_weight is not None:
-            w = torch.ones_like(ce)
-            w[gt_classes == self.num_classes] = self.bg_cls_loss_weight
-            ce = ce * w
-        loss_cls = ce.mean()
+        loss_cls = layers.focal_cross_entropy(scores, gt_classes, self.focal_scaled_loss, self.num_classes, self.bg_cls_loss_weight)
         fg = torch.nonzero((gt_classes >= 0) & (gt_classes < self.num_classes), as_tuple=True)[0]
         fg_pred = deltas.view(-1, self.num_classes, 4)[fg, gt_classes[fg]]
         gt_d = get_deltas(pboxes[fg], gboxes[fg], self.box_weights)

@@ -82,6 +82,16 @@ int cddmsl_cosine_logits_fwd(const float* x, const float* wn, float* scores, flo
                              float temperature, float eps, void* stream);
 int cddmsl_cosine_logits_bwd(const float* ds, const float* x, const float* wn, const float* inv, float* dx, long R, int D,
                              int Kc, float temperature, int accumulate, void* stream);
+/* mapper LayerNorm (modeling/backbone/clipcap/clipcap.py:97-100; frozen affine) and the focal-scaled, background-weighted
+ * classification loss (modeling/roi_heads/fast_rcnn.py:624-644): row_loss = CE * (1-p_t)^gamma * w; probs saved for backward */
+int cddmsl_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, long R, int D,
+                         float eps, int dtype, void* stream);
+int cddmsl_layernorm_bwd(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                         long R, int D, int accumulate, int dtype, void* stream);
+int cddmsl_focal_ce_fwd(const float* logits, const long* target, float* row_loss, float* probs, long R, int C, float gamma,
+                        int bg_class, float bg_weight, void* stream);
+int cddmsl_focal_ce_bwd(const float* logits, const long* target, const float* probs, const float* gscale, float* dlogits, long R,
+                        int C, float gamma, int bg_class, float bg_weight, void* stream);
 int cddmsl_contrastive_fwd(const float* S, float* rlse, float* clse, float* loss, int n, int ld, void* stream);
 int cddmsl_contrastive_bwd(const float* S, const float* rlse, const float* clse, const float* gloss, float* dS, int n, int ld,
                            void* stream);

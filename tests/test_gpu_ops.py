@@ -238,3 +238,32 @@ def test_sgd_clip_step():
     for i in range(len(ps)):
         assert (P[i].cpu() - sd[str(i)]).abs().max() < 1e-6
         assert (M[i].cpu() - mom[str(i)]).abs().max() < 1e-5
+
+
+def test_layernorm_and_focal_ce():
+    from cddmsl_amd import hip, layers, synthetic
+    from oracle import model as om
+    x = _rand((37, 768), 1).requires_grad_(True)
+    g, b = 1.0 + 0.1 * _rand((768,), 2), 0.1 * _rand((768,), 3)
+    ref = F.layer_norm(x, (768,), g, b)
+    w = _rand((37, 768), 4)
+    (ref * w).sum().backward()
+    xg = x.detach().cuda().requires_grad_(True)
+    y = layers.layer_norm(xg, g.cuda(), b.cuda(), torch.float32)
+    assert (y.cpu() - ref.detach()).abs().max() < 1e-5
+    (y * w.cuda()).sum().backward()
+    assert (xg.grad.cpu() - x.grad).abs().max() < 1e-5 * max(1.0, float(x.grad.abs().max()))
+    yb = layers.layer_norm(x.detach().cuda(), g.cuda(), b.cuda(), torch.bfloat16)
+    assert yb.dtype == torch.bfloat16 and (yb.float().cpu() - ref.detach()).abs().max() < 3e-2
+
+    cfg = om.Cfg()
+    s = (_rand((61, 21), 5) * 30).requires_grad_(True)
+    t = torch.randint(0, 21, (61,), generator=torch.Generator().manual_seed(6))
+    t[:7] = 20
+    ref_l = om.focal_loss(cfg, s, t)
+    ref_l.backward()
+    sg = s.detach().cuda().requires_grad_(True)
+    l = layers.focal_cross_entropy(sg, t.cuda(), cfg.focal_gamma, cfg.num_classes, cfg.bg_cls_loss_weight)
+    l.backward()
+    assert abs(float(l) - float(ref_l)) < 1e-5 * abs(float(ref_l))
+    assert (sg.grad.cpu() - s.grad).abs().max() < 1e-5 * float(s.grad.abs().max()) + 1e-9
