@@ -150,9 +150,10 @@ __global__ void k_avgpool2_bwd(const char* dy, const char* mask, const char* add
 }
 
 // ---------------------------------------------------------------- attention-pool tokens
-// x [K][P][C] (P = 49 pixels) -> tok [K][P+1][C]: tok0 = mean_p x + pos[0], tok_{i+1} = x_i + pos[i+1]
+// x [K][P][C] (P = 49 pixels) -> tok [K][TP][C] (TP >= P+1 token rows per region in memory; rows P+1.. are zero):
+// tok0 = mean_p x + pos[0], tok_{i+1} = x_i + pos[i+1]
 template <typename T>
-__global__ void k_attn_tokens_fwd(const char* x, const float* pos, char* tok, int K, int P, int cch) {
+__global__ void k_attn_tokens_fwd(const char* x, const float* pos, char* tok, int K, int P, int TP, int cch) {
   long total = (long)K * cch;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = i % cch; long k = i / cch;
@@ -163,24 +164,26 @@ __global__ void k_attn_tokens_fwd(const char* x, const float* pos, char* tok, in
       const float* pe = pos + (long)(p + 1) * cch * VEC + c * VEC;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { s[j] += v[j]; o[j] = v[j] + pe[j]; }
-      ((u32x4*)tok)[(k * (P + 1) + p + 1) * cch + c] = Elt<T>::pack(o);
+      ((u32x4*)tok)[(k * TP + p + 1) * cch + c] = Elt<T>::pack(o);
     }
     const float* pe = pos + c * VEC;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o[j] = s[j] / (float)P + pe[j];
-    ((u32x4*)tok)[(k * (P + 1)) * cch + c] = Elt<T>::pack(o);
+    ((u32x4*)tok)[(k * TP) * cch + c] = Elt<T>::pack(o);
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int p = P + 1; p < TP; ++p) ((u32x4*)tok)[(k * TP + p) * cch + c] = z;
   }
 }
 // dx[k][p] = dtok[k][p+1] + dtok[k][0]/P
 template <typename T>
-__global__ void k_attn_tokens_bwd(const char* dtok, char* dx, int K, int P, int cch) {
+__global__ void k_attn_tokens_bwd(const char* dtok, char* dx, int K, int P, int TP, int cch) {
   long total = (long)K * P * cch;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = i % cch; long q = i / cch;
     int p = q % P; long k = q / P;
     float a[8], b[8], o[8];
-    Elt<T>::unpack(((const u32x4*)dtok)[(k * (P + 1) + p + 1) * cch + c], a);
-    Elt<T>::unpack(((const u32x4*)dtok)[(k * (P + 1)) * cch + c], b);
+    Elt<T>::unpack(((const u32x4*)dtok)[(k * TP + p + 1) * cch + c], a);
+    Elt<T>::unpack(((const u32x4*)dtok)[(k * TP) * cch + c], b);
 #pragma unroll
     for (int j = 0; j < Elt<T>::VEC; ++j) o[j] = a[j] + b[j] / (float)P;
     ((u32x4*)dx)[i] = Elt<T>::pack(o);
@@ -311,23 +314,23 @@ extern "C" int cddmsl_avgpool2_bwd(const void* dy, const void* mask, const void*
   return launch_status();
 }
 
-extern "C" int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int C, int dtype, void* stream) {
+extern "C" int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int TP, int C, int dtype, void* stream) {
   int es = dtype == 0 ? 2 : 4;
-  if ((C * es) % 16 || P <= 0) return CDDMSL_ERR_ARG;
+  if ((C * es) % 16 || P <= 0 || TP < P + 1) return CDDMSL_ERR_ARG;
   int cch = C * es / 16;
   long total = (long)K * cch;
   if (total == 0) return CDDMSL_OK;
-  DISPATCH(dtype, k_attn_tokens_fwd, <<<dim3(gsz(total, 64)), dim3(64), 0, (hipStream_t)stream>>>((const char*)x, pos, (char*)tok, K, P, cch));
+  DISPATCH(dtype, k_attn_tokens_fwd, <<<dim3(gsz(total, 64)), dim3(64), 0, (hipStream_t)stream>>>((const char*)x, pos, (char*)tok, K, P, TP, cch));
   return launch_status();
 }
 
-extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, int C, int dtype, void* stream) {
+extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, int TP, int C, int dtype, void* stream) {
   int es = dtype == 0 ? 2 : 4;
-  if ((C * es) % 16 || P <= 0) return CDDMSL_ERR_ARG;
+  if ((C * es) % 16 || P <= 0 || TP < P + 1) return CDDMSL_ERR_ARG;
   int cch = C * es / 16;
   long total = (long)K * P * cch;
   if (total == 0) return CDDMSL_OK;
-  DISPATCH(dtype, k_attn_tokens_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (char*)dx, K, P, cch));
+  DISPATCH(dtype, k_attn_tokens_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (char*)dx, K, P, TP, cch));
   return launch_status();
 }
 

@@ -58,6 +58,8 @@ struct ConvArgs {
   int relu, out_f32, pool;
   int M, Kc, cpp;  // rows, total K chunks, chunks per pixel
   FastDiv dWo, dHo, dcpp, dKW;
+  int xrs, wrs;    // row strides in 16-byte chunks: A pixel -> pixel (default cpp), B row -> row (default Kc)
+  long bx, bw, by; // byte strides of the batch axis (gridDim.y); 0 for plain convolutions
 };
 
 template <typename T> struct Mma;
@@ -325,6 +327,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][BM * KCH];   // [buffer][A|B]
   const int t = threadIdx.x;
+  p.x += (long)blockIdx.y * p.bx; p.w += (long)blockIdx.y * p.bw; p.y += (long)blockIdx.y * p.by;   // batched GEMM
   const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);     // wave index in an SGPR: LDS-DMA bases become scalar
   const int ntn = (p.Cout + BN - 1) / BN;
   const int lbid = xcd_remap(blockIdx.x, gridDim.x);
@@ -346,10 +349,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
     unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
     iy0[i] = (int)oy * p.stride - p.pad;
     ix0[i] = (int)ox * p.stride - p.pad;
-    rowoff[i] = ((((long)img * p.Hi + iy0[i]) * p.Wi + ix0[i]) * p.cpp) * 16;
+    rowoff[i] = ((((long)img * p.Hi + iy0[i]) * p.Wi + ix0[i]) * p.xrs) * 16;
     int n = n0 + rb + 32 * i;
     vn[i] = n < p.Cout;
-    wrow[i] = (long)(vn[i] ? n : 0) * p.Kc * 16;
+    wrow[i] = (long)(vn[i] ? n : 0) * p.wrs * 16;
   }
   const int nkt = (p.Kc + KCH - 1) / KCH;
   const char* zp = (const char*)g_zero_page;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   int inca[4], incb[4];
   int tiles_left_in_tap = 0;                    // K-tiles before (ky,kx) advances (fast path)
   auto retap = [&]() {                          // (re)build the A pointers for the current (ky, kx, coff)
-    const int delta = ((ky * p.Wi + kx) * p.cpp + coff) * 16;
+    const int delta = ((ky * p.Wi + kx) * p.xrs + coff) * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bool ok = vm[i];
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
       return;
     }
     const bool vk = kc < p.Kc;
-    const int delta = ((ky * p.Wi + kx) * p.cpp + coff) * 16;
+    const int delta = ((ky * p.Wi + kx) * p.xrs + coff) * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       bool ok = vk && vm[i];
@@ -585,6 +588,10 @@ struct WgradArgs {
   int M, Kc, cpp, K, ncc;  // ncc = chunks per dY row that exist (Cout*ES/16)
   int mtiles_per_split;
   FastDiv dWo, dHo;
+  int xrs;            // x row stride in chunks (default cpp)
+  int ldo;            // output row stride in elements (default K)
+  int direct;         // 0: f32 atomicAdd (split reductions); 1: plain f32 store; 2: plain T store (single split only)
+  long bx, bd, bo;    // batch (gridDim.y) byte strides of x, dy, out
 };
 
 constexpr int WM = 64;                 // m rows per reduction tile
@@ -805,6 +812,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_dma(WgradArgs p) {
   constexpr int COLS = 256 / ES;
   __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][WM * 16];   // [buffer][dY | X][64 rows x 16 chunks]
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  p.x += (long)blockIdx.y * p.bx; p.dy += (long)blockIdx.y * p.bd;
+  char* outp = (char*)p.dw + (long)blockIdx.y * p.bo;
   const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ntn = (p.Cout + COLS - 1) / COLS, ntk = (p.K + COLS - 1) / COLS;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -834,9 +843,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_dma(WgradArgs p) {
   for (int i = 0; i < 4; ++i) {
     m[i] = mt0 * WM + rb + 16 * i;
     pd[i] = p.dy + ((long)m[i] * p.ldd) * ES + (long)nc * 16;
-    px[i] = p.x + (((long)m[i] + (long)(ky - p.pad) * p.Wi + (kx - p.pad)) * p.cpp + coff) * 16;
+    px[i] = p.x + (((long)m[i] + (long)(ky - p.pad) * p.Wi + (kx - p.pad)) * p.xrs) * 16 + (long)coff * 16;
   }
-  const long dstep = (long)WM * p.ldd * ES, xstep = (long)WM * p.cpp * 16;
+  const long dstep = (long)WM * p.ldd * ES, xstep = (long)WM * p.xrs * 16;
 
   auto stage = [&](int buf) {
 #pragma unroll
@@ -919,7 +928,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_dma(WgradArgs p) {
         int n = n0 + wn * WT + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         if (n >= p.Cout) continue;
         float v = acc[a][b][g] * (p.scale ? p.scale[n] : 1.f);
-        atomicAdd(p.dw + (long)n * p.K + k, v);
+        long o = (long)n * p.ldo + k;
+        if (p.direct == 0) atomicAdd((float*)outp + o, v);
+        else if (p.direct == 1) ((float*)outp)[o] = v;
+        else Mma<T>::store(outp + o * ES, v);
       }
     }
 }
@@ -945,13 +957,15 @@ __global__ void k_weight_prep(const float* w, const float* scale, char* wf, char
   }
 }
 
+static thread_local int g_batch = 1;   // set by the batched entry point around its launch
+
 template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   int ntn = (a.Cout + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
   long grid = (long)ntn * ntm;
   if (grid <= 0) return CDDMSL_OK;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   if (a.pool) hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid, (unsigned)g_batch), dim3(256), 0, st, a);
   return launch_status();
 }
 
@@ -979,6 +993,7 @@ extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const floa
   a.M = (int)M; a.cpp = Cin * es / 16; a.Kc = KH * KW * a.cpp;
   a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
   a.dcpp = make_fastdiv((unsigned)a.cpp); a.dKW = make_fastdiv((unsigned)KW);
+  a.xrs = a.cpp; a.wrs = a.Kc; a.bx = a.bw = a.by = 0;
   if (a.M == 0) return CDDMSL_OK;
   return dtype == 0 ? conv_fwd_launch<__bf16>(a, (hipStream_t)stream) : conv_fwd_launch<float>(a, (hipStream_t)stream);
 }
@@ -1002,6 +1017,7 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
   a.M = (int)M; a.cpp = Cin * es / 16; a.Kc = KH * KW * a.cpp; a.K = KH * KW * Cin; a.ncc = Cout * es / 16;
   a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
+  a.xrs = a.cpp; a.ldo = a.K; a.direct = 0; a.bx = a.bd = a.bo = 0;
   if (a.M == 0) return CDDMSL_OK;
   int cols = 256 / es;
   long tiles = (long)((Cout + cols - 1) / cols) * ((a.K + cols - 1) / cols);
@@ -1023,6 +1039,65 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
     if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_conv_wgrad<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   }
+  return launch_status();
+}
+
+// Batched "NT" GEMM on the conv kernel: for b in [0,batch): C_b[m][n] = sum_k A_b[m][k] * B_b[n][k] (+ bias[n]),
+// A_b = a + b*sa, rows lda apart; B_b = w + b*sw, rows ldb apart; C_b = c + b*sc, rows ldc apart (strides in ELEMENTS).
+// Used by the reassociated attention pool (per-head and per-region products).
+extern "C" int cddmsl_gemm_nt_batched(const void* a, const void* w, void* c, const float* bias, int M, int N, int K, int lda,
+                                      int ldb, int ldc, int batch, long sa, long sw, long sc, int out_f32, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if (dtype != 0 && dtype != 1) return CDDMSL_ERR_ARG;
+  if (M < 0 || N <= 0 || K <= 0 || batch < 0 || batch > 65535) return CDDMSL_ERR_ARG;
+  if ((K * es) % 16 || (lda * es) % 16 || (ldb * es) % 16 || (sa * es) % 16 || (sw * es) % 16) return CDDMSL_ERR_ARG;
+  if (M == 0 || batch == 0) return CDDMSL_OK;
+  ConvArgs p;
+  p.x = (const char*)a; p.w = (const char*)w; p.y = (char*)c; p.scale = nullptr; p.bias = bias; p.residual = nullptr; p.relu_mask = nullptr;
+  p.Nimg = 1; p.Hi = 1; p.Wi = M; p.Cin = K; p.Ho = 1; p.Wo = M; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+  p.ldy = ldc; p.ldr = 0; p.ldm = 0; p.relu = 0; p.out_f32 = out_f32; p.pool = 0;
+  p.M = M; p.cpp = K * es / 16; p.Kc = p.cpp;
+  p.dWo = make_fastdiv((unsigned)M); p.dHo = make_fastdiv(1u); p.dcpp = make_fastdiv((unsigned)p.cpp); p.dKW = make_fastdiv(1u);
+  p.xrs = lda * es / 16; p.wrs = ldb * es / 16;
+  p.bx = sa * es; p.bw = sw * es; p.by = sc * (out_f32 ? 4 : es);
+  g_batch = batch;
+  int st = dtype == 0 ? conv_fwd_launch<__bf16>(p, (hipStream_t)stream) : conv_fwd_launch<float>(p, (hipStream_t)stream);
+  g_batch = 1;
+  return st;
+}
+
+// Batched "TN" GEMM on the LDS-DMA wgrad kernel: out_b[n][k] (+)= sum_m A_b[m][n] * B_b[m][k]; A rows lda apart (n contiguous),
+// B rows ldb apart (k contiguous), out rows ldo apart.  mode 0: f32 atomic accumulate (large M is split over blocks),
+// 1: f32 store, 2: `dtype` store (modes 1/2 need M <= 64*8 so one block owns a tile... enforced: single split).
+extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, int M, int N, int K, int lda, int ldb, int ldo,
+                                      int batch, long sa, long sb, long so, int mode, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if (dtype != 0 && dtype != 1) return CDDMSL_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535 || mode < 0 || mode > 2) return CDDMSL_ERR_ARG;
+  if ((K * es) % 16 || (N * es) % 16 || (lda * es) % 16 || (ldb * es) % 16 || (sa * es) % 16 || (sb * es) % 16) return CDDMSL_ERR_ARG;
+  WgradArgs p;
+  p.x = (const char*)b; p.dy = (const char*)a; p.dw = (float*)out; p.scale = nullptr;
+  p.Nimg = 1; p.Hi = 1; p.Wi = M; p.Cin = K; p.Ho = 1; p.Wo = M; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+  p.ldd = lda; p.pool = 0; p.M = M; p.cpp = K * es / 16; p.Kc = p.cpp; p.K = K; p.ncc = N * es / 16;
+  p.dWo = make_fastdiv((unsigned)M); p.dHo = make_fastdiv(1u);
+  p.xrs = ldb * es / 16; p.ldo = ldo; p.direct = mode;
+  p.bx = sb * es; p.bd = sa * es; p.bo = so * (mode == 2 ? es : 4);
+  int cols = 256 / es;
+  long tiles = (long)((N + cols - 1) / cols) * ((K + cols - 1) / cols);
+  int total_mt = (M + WM - 1) / WM;
+  long splits = 1;
+  if (mode == 0) {
+    long want = (2048 + tiles * batch - 1) / (tiles * batch);
+    long maxs = (total_mt + 7) / 8;
+    splits = want < 1 ? 1 : (want > maxs ? maxs : want);
+    if (splits < 1) splits = 1;
+  }
+  p.mtiles_per_split = (int)((total_mt + splits - 1) / splits);
+  splits = (total_mt + p.mtiles_per_split - 1) / p.mtiles_per_split;
+  long grid = tiles * splits;
+  if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();
 }
 

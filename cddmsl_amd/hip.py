@@ -27,8 +27,10 @@ def _L():
         L.cddmsl_preprocess224.argtypes = [vp, vp] + [ci] * 11 + [vp, vp, ci, vp]
         L.cddmsl_avgpool2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
         L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
-        L.cddmsl_attn_tokens_fwd.argtypes = [vp] * 3 + [ci] * 4 + [vp]
-        L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 2 + [ci] * 4 + [vp]
+        L.cddmsl_attn_tokens_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
+        L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 2 + [ci] * 5 + [vp]
+        L.cddmsl_gemm_nt_batched.argtypes = [vp] * 4 + [ci] * 7 + [c_long] * 3 + [ci, ci, vp]
+        L.cddmsl_gemm_tn_batched.argtypes = [vp] * 3 + [ci] * 7 + [c_long] * 3 + [ci, ci, vp]
         L.cddmsl_relu_bwd.argtypes = [vp, vp, vp, c_long, ci, ci, vp]
         L.cddmsl_colsum.argtypes = [vp, vp, c_long, ci, ci, ci, vp]
         L.cddmsl_sgd_clip_step.argtypes = [vp] * 4 + [ci, vp] + [cf] * 4 + [ci, vp]
@@ -39,8 +41,6 @@ def _L():
         L.cddmsl_rpn_decode.argtypes = [vp] * 6 + [ci] * 5 + [cf] * 8 + [vp]
         L.cddmsl_nms.argtypes = [vp] * 5 + [ci, ci, cf, ci, vp]
         L.cddmsl_iou_match.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, cf, cf, ci, ci, ci, ci, vp]
-        L.cddmsl_attnpool_core_fwd.argtypes = [vp] * 4 + [ci, ci, ci, cf, ci, vp]
-        L.cddmsl_attnpool_core_bwd.argtypes = [vp] * 6 + [ci, ci, ci, cf, ci, vp]
         L.cddmsl_l2norm_fwd.argtypes = [vp, vp, vp, c_long, ci, cf, vp]
         L.cddmsl_l2norm_bwd.argtypes = [vp, vp, vp, vp, c_long, ci, vp]
         L.cddmsl_cosine_logits_fwd.argtypes = [vp] * 4 + [c_long, ci, ci, cf, cf, vp]
@@ -258,23 +258,57 @@ def avgpool2_bwd(dy, in_shape, mask=None, add=None):
 
 
 @_timed("attn_tokens_fwd")
-def attn_tokens_fwd(x, pos):
-    """x [K,P,C] (T), pos [P+1,C] f32 -> tok [K,P+1,C]"""
+def attn_tokens_fwd(x, pos, tp=None):
+    """x [K,P,C] (T), pos [P+1,C] f32 -> tok [K,TP,C] (TP >= P+1 token rows per region; pad rows are zero)"""
     require_cuda(x, pos)
     K, P, C = x.shape
+    tp = tp or P + 1
     assert pos.dtype == torch.float32 and tuple(pos.shape) == (P + 1, C) and x.is_contiguous() and pos.is_contiguous()
-    tok = torch.empty((K, P + 1, C), device=x.device, dtype=x.dtype)
-    check(_L().cddmsl_attn_tokens_fwd(ptr(x), ptr(pos), ptr(tok), K, P, C, _dt(x), stream_ptr()), "cddmsl_attn_tokens_fwd")
+    tok = torch.empty((K, tp, C), device=x.device, dtype=x.dtype)
+    check(_L().cddmsl_attn_tokens_fwd(ptr(x), ptr(pos), ptr(tok), K, P, tp, C, _dt(x), stream_ptr()), "cddmsl_attn_tokens_fwd")
     return tok
 
 
 @_timed("attn_tokens_bwd")
-def attn_tokens_bwd(dtok):
+def attn_tokens_bwd(dtok, P):
+    """dtok [K,TP,C] -> dx [K,P,C]"""
     require_cuda(dtok)
-    K, P1, C = dtok.shape
-    dx = torch.empty((K, P1 - 1, C), device=dtok.device, dtype=dtok.dtype)
-    check(_L().cddmsl_attn_tokens_bwd(ptr(dtok), ptr(dx), K, P1 - 1, C, _dt(dtok), stream_ptr()), "cddmsl_attn_tokens_bwd")
+    K, TP, C = dtok.shape
+    assert dtok.is_contiguous()
+    dx = torch.empty((K, P, C), device=dtok.device, dtype=dtok.dtype)
+    check(_L().cddmsl_attn_tokens_bwd(ptr(dtok), ptr(dx), K, P, TP, C, _dt(dtok), stream_ptr()), "cddmsl_attn_tokens_bwd")
     return dx
+
+
+def _eptr(t, elem_offset=0):
+    return ctypes.c_void_p(t.data_ptr() + elem_offset * t.element_size())
+
+
+@_timed("gemm_nt_batched")
+def gemm_nt_batched(a, w, c, M, N, K, lda, ldb, ldc, batch, sa, sw, sc, a_off=0, w_off=0, c_off=0, bias=None):
+    """C_b[m][n] = sum_k A_b[m][k] * B_b[n][k] for b < batch; raw strided views of the tensors a, w, c (element offsets /
+    strides).  c's dtype decides f32 vs compute-dtype output."""
+    require_cuda(a, w, c, bias)
+    assert a.dtype == w.dtype and c.dtype in (a.dtype, torch.float32)
+    out_f32 = int(c.dtype == torch.float32 and a.dtype != torch.float32)
+    check(_L().cddmsl_gemm_nt_batched(_eptr(a, a_off), _eptr(w, w_off), _eptr(c, c_off), ptr(bias), M, N, K, lda, ldb, ldc, batch,
+                                      sa, sw, sc, out_f32, _dt(a), stream_ptr()), "cddmsl_gemm_nt_batched")
+
+
+@_timed("gemm_tn_batched")
+def gemm_tn_batched(a, b, out, M, N, K, lda, ldb, ldo, batch, sa, sb, so, a_off=0, b_off=0, o_off=0, accumulate=False):
+    """out_b[n][k] (+)= sum_m A_b[m][n] * B_b[m][k].  accumulate=True: f32 atomic adds into `out` (f32); otherwise a plain
+    store in out's dtype (f32 or the compute dtype)."""
+    require_cuda(a, b, out)
+    assert a.dtype == b.dtype
+    if accumulate:
+        assert out.dtype == torch.float32
+        mode = 0
+    else:
+        mode = 1 if (out.dtype == torch.float32 and a.dtype != torch.float32) else (1 if out.dtype == torch.float32 else 2)
+        assert out.dtype in (a.dtype, torch.float32)
+    check(_L().cddmsl_gemm_tn_batched(_eptr(a, a_off), _eptr(b, b_off), _eptr(out, o_off), M, N, K, lda, ldb, ldo, batch, sa, sb, so,
+                                      mode, _dt(a), stream_ptr()), "cddmsl_gemm_tn_batched")
 
 
 @_timed("relu_bwd")
@@ -446,31 +480,6 @@ def iou_match(gt, preds, thresholds, labels, allow_low_quality):
 
 
 # ------------------------------------------------------------------------------------------------ attention pool / losses
-@_timed("attnpool_core_fwd")
-def attnpool_core_fwd(q0, kv, heads):
-    require_cuda(q0, kv)
-    K, C = q0.shape
-    T = kv.shape[1]
-    assert kv.shape == (K, T, 2 * C) and C == heads * 64 and q0.is_contiguous() and kv.is_contiguous()
-    o = torch.empty((K, C), device=q0.device, dtype=q0.dtype)
-    p = torch.empty((K, heads, T), device=q0.device, dtype=torch.float32)
-    check(_L().cddmsl_attnpool_core_fwd(ptr(q0), ptr(kv), ptr(o), ptr(p), K, T, heads, 64 ** -0.5, _dt(q0), stream_ptr()),
-          "cddmsl_attnpool_core_fwd")
-    return o, p
-
-
-@_timed("attnpool_core_bwd")
-def attnpool_core_bwd(dO, q0, kv, p, heads):
-    require_cuda(dO, q0, kv, p)
-    K, C = q0.shape
-    T = kv.shape[1]
-    dq0 = torch.empty_like(q0)
-    dkv = torch.empty_like(kv)
-    check(_L().cddmsl_attnpool_core_bwd(ptr(dO.contiguous()), ptr(q0), ptr(kv), ptr(p), ptr(dq0), ptr(dkv), K, T, heads, 64 ** -0.5,
-                                         _dt(q0), stream_ptr()), "cddmsl_attnpool_core_bwd")
-    return dq0, dkv
-
-
 def l2norm_fwd(x, eps):
     require_cuda(x)
     R, D = x.shape

@@ -294,67 +294,112 @@ class AttnPoolParams:
 
 
 class AttnPoolFn(torch.autograd.Function):
+    """Query-0-only attention pool, reassociated so that no per-token K/V projection is ever formed:
+
+        scores[h,t] = q0_h . (Wk_h tok_t + bk_h)  =  (Wk_h^T q0_h) . tok_t  + const_h      (const drops out of softmax)
+        out_h       = sum_t p[h,t] (Wv_h tok_t + bv_h)  =  Wv_h (sum_t p[h,t] tok_t) + bv_h
+
+    i.e. u = per-head GEMM [K,64]x[64,C], scores = per-region GEMM [H,C]x[C,T], z = per-region GEMM [H,T]x[T,C],
+    o = per-head GEMM [K,C]x[C,64]: ~20x fewer FLOPs than projecting K and V for all 50 tokens (the reference projects
+    q, k, v for all tokens and keeps token 0, clip_backbone.py:83-107).  All products run on the batched MFMA GEMMs;
+    the 50-wide softmax and its backward are fp32 elementwise glue.  Token rows per region are padded 50 -> 56
+    (whole 16-byte chunks for the transposed products); pad rows are zero."""
+
+    TP = 56
+
     @staticmethod
     def forward(ctx, x, anchor, ap):
         """x [K,h,w,C] NHWC T with h*w+1 == len(pos)  ->  [K, out_dim] f32"""
         T = x.dtype
         K, h, w, C = x.shape
-        P = h * w
-        assert ap.pos.shape[0] == P + 1, "attention pool needs a 7x7 map (clip_backbone.py:86)"
-        tok = hip.attn_tokens_fwd(x.view(K, P, C), ap.pos.detach())
-        wk, _ = ap.pk.get(T, False)
-        wv, _ = ap.pv.get(T, False)
+        P, TP, H = h * w, AttnPoolFn.TP, ap.heads
+        D = C // H
+        assert ap.pos.shape[0] == P + 1 <= TP, "attention pool needs a 7x7 map (clip_backbone.py:86)"
+        dev = x.device
+        tok = hip.attn_tokens_fwd(x.view(K, P, C), ap.pos.detach(), TP)                      # [K,TP,C]
         wq, _ = ap.pq.get(T, False)
+        wk, wkT = ap.pk.get(T, True)                                                          # [C,1,1,C]: rows = hd ; rows = c
+        wv, wvT = ap.pv.get(T, True)
         wc, _ = ap.pc.get(T, False)
-        wkv = torch.cat([wk, wv], dim=0)
-        bkv = torch.cat([ap.k_b.detach(), ap.v_b.detach()])
-        kv = hip.conv_fwd(tok.view(1, 1, K * (P + 1), C), wkv, None, bkv).view(K, P + 1, 2 * C)
-        # token-0 rows only: a 1x1 "conv" over [K,1,P+1,C] with stride P+1 picks row 0 of every region
-        q0 = hip.conv_fwd(tok.view(K, 1, P + 1, C), wq, None, ap.q_b.detach(), stride=P + 1).view(K, C)
-        o, p = hip.attnpool_core_fwd(q0, kv, ap.heads)
+        q0 = hip.conv_fwd(tok.view(K, 1, TP, C), wq, None, ap.q_b.detach(), stride=TP).view(K, C)
+        # zu[:, :H] = dZ (backward), zu[:, H:] = U : one buffer so the backward's dtok product is a single GEMM
+        zu = torch.empty((K, 2 * H, C), device=dev, dtype=T)
+        # U[k,h,:] = q0[k, hD:(h+1)D] @ Wk[hD:(h+1)D, :]        (per-head, contraction 64)
+        hip.gemm_nt_batched(q0, wkT, zu, K, C, D, C, C, 2 * H * C, H, D, D, C, c_off=H * C)
+        # S[k] = U[k] (H x C) . tok[k]^T (C x TP)
+        S = torch.empty((K, H, TP), device=dev, dtype=torch.float32)
+        hip.gemm_nt_batched(zu, tok, S, H, TP, C, C, C, TP, K, 2 * H * C, TP * C, H * TP, a_off=H * C)
+        p = torch.softmax(S[:, :, :P + 1] * (D ** -0.5), dim=-1)                              # [K,H,P+1] f32
+        pT = torch.zeros((K, TP, H), device=dev, dtype=T)
+        pT[:, :P + 1] = p.transpose(1, 2)
+        # Z[k] (H x C) = P[k] (H x TP) . tok[k] (TP x C)      (reduction over token rows)
+        z = torch.empty((K, H, C), device=dev, dtype=T)
+        hip.gemm_tn_batched(pT, tok, z, TP, H, C, H, C, C, K, TP * H, TP * C, H * C)
+        # o[k, hD:(h+1)D] = Z[k,h,:] @ Wv[hD:(h+1)D, :]^T    (+ bv)
+        o = torch.empty((K, C), device=dev, dtype=T)
+        hip.gemm_nt_batched(z, wv, o, K, D, C, H * C, C, C, H, C, D * C, D)
+        o = o + ap.v_b.detach().to(T)
         out = hip.conv_fwd(o.view(1, 1, K, C), wc, None, ap.c_b.detach(), out_f32=True).view(K, -1)
         ctx.ap = ap
-        ctx.save_for_backward(tok, kv, q0, o, p)
+        ctx.save_for_backward(tok, q0, zu, p, z, o)
         ctx.shape = (K, h, w, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ap = ctx.ap
-        tok, kv, q0, o, p = ctx.saved_tensors
+        tok, q0, zu, p, z, o = ctx.saved_tensors
         K, h, w, C = ctx.shape
-        P = h * w
+        P, TP, H = h * w, AttnPoolFn.TP, ap.heads
+        D = C // H
         T = tok.dtype
-        dout_t = dout.contiguous().to(T)
+        dev = tok.device
         train = not ap.frozen
+        dout_t = dout.contiguous().to(T)
         if train:
             hip.conv_wgrad(o.view(1, 1, K, C), dout_t.view(1, 1, K, -1), _ohwi(ap.c_w).shape, out=_ohwi(_grad_buf(ap.c_w)))
             hip.colsum(dout_t, out=_grad_buf(ap.c_b))
         _, wcd = ap.pc.get(T, True)
+        wk, wkT = ap.pk.get(T, True)
+        wv, wvT = ap.pv.get(T, True)
         do = hip.conv_fwd(dout_t.view(1, 1, K, -1), wcd).view(K, C)
-        dq0, dkv = hip.attnpool_core_bwd(do, q0, kv, p, ap.heads)
-        tok4 = tok.view(1, 1, K * (P + 1), C)
-        dkv4 = dkv.view(1, 1, K * (P + 1), 2 * C)
         if train:
-            dk = dkv[:, :, :C].contiguous().view(1, 1, -1, C)
-            dv = dkv[:, :, C:].contiguous().view(1, 1, -1, C)
-            hip.conv_wgrad(tok4, dk, _ohwi(ap.k_w).shape, out=_ohwi(_grad_buf(ap.k_w)))
-            hip.conv_wgrad(tok4, dv, _ohwi(ap.v_w).shape, out=_ohwi(_grad_buf(ap.v_w)))
-            gb = hip.colsum(dkv.view(-1, 2 * C))
-            _grad_buf(ap.k_b).add_(gb[:C])
-            _grad_buf(ap.v_b).add_(gb[C:])
-            hip.conv_wgrad(tok.view(K, 1, P + 1, C), dq0.view(K, 1, 1, C), _ohwi(ap.q_w).shape, stride=P + 1,
-                           out=_ohwi(_grad_buf(ap.q_w)))
+            hip.colsum(do, out=_grad_buf(ap.v_b))
+            # dWv[hD:(h+1)D, :] += dO[:, hD:(h+1)D]^T @ Z[:,h,:]      (reduction over regions, f32 atomics)
+            hip.gemm_tn_batched(do, z, _grad_buf(ap.v_w), K, D, C, C, H * C, C, H, D, C, D * C, accumulate=True)
+        # dZ[k,h,:] = dO[k, hD:(h+1)D] @ Wv[hD:(h+1)D, :]  -> zu[:, :H]
+        hip.gemm_nt_batched(do, wvT, zu, K, C, D, C, C, 2 * H * C, H, D, D, C)
+        # dP[k] = dZ[k] . tok[k]^T ; softmax backward in fp32
+        dP = torch.empty((K, H, TP), device=dev, dtype=torch.float32)
+        hip.gemm_nt_batched(zu, tok, dP, H, TP, C, C, C, TP, K, 2 * H * C, TP * C, H * TP)
+        dp = dP[:, :, :P + 1]
+        ds = p * (dp - (p * dp).sum(dim=-1, keepdim=True)) * (D ** -0.5)                    # [K,H,P+1] f32
+        # dU[k] (H x C) = dS[k] (H x TP) . tok[k]
+        dsT = torch.zeros((K, TP, H), device=dev, dtype=T)
+        dsT[:, :P + 1] = ds.transpose(1, 2)
+        du = torch.empty((K, H, C), device=dev, dtype=T)
+        hip.gemm_tn_batched(dsT, tok, du, TP, H, C, H, C, C, K, TP * H, TP * C, H * C)
+        # dtok[k] (TP x C) = [P[k]; dS[k]]^T (TP x 2H) . [dZ[k]; U[k]] (2H x C)     (reduction over the 2H stacked rows)
+        pds = torch.zeros((K, 2 * H, TP), device=dev, dtype=T)
+        pds[:, :H, :P + 1] = p
+        pds[:, H:, :P + 1] = ds
+        dtok = torch.empty((K, TP, C), device=dev, dtype=T)
+        hip.gemm_tn_batched(pds, zu, dtok, 2 * H, TP, C, TP, C, C, K, 2 * H * TP, 2 * H * C, TP * C)
+        # dq0[k, hD:(h+1)D] = dU[k,h,:] @ Wk[hD:(h+1)D, :]^T
+        dq0 = torch.empty((K, C), device=dev, dtype=T)
+        hip.gemm_nt_batched(du, wk, dq0, K, D, C, H * C, C, C, H, C, D * C, D)
+        if train:
+            # dWk[hD:(h+1)D, :] += q0[:, hD:(h+1)D]^T @ dU[:,h,:]   (k_proj.bias has an exactly-zero gradient)
+            hip.gemm_tn_batched(q0, du, _grad_buf(ap.k_w), K, D, C, C, H * C, C, H, D, C, D * C, accumulate=True)
+            _grad_buf(ap.k_b)
+            hip.conv_wgrad(tok.view(K, 1, TP, C), dq0.view(K, 1, 1, C), _ohwi(ap.q_w).shape, stride=TP, out=_ohwi(_grad_buf(ap.q_w)))
             hip.colsum(dq0, out=_grad_buf(ap.q_b))
-        _, wkd = ap.pk.get(T, True)
-        _, wvd = ap.pv.get(T, True)
-        wkvd = torch.cat([wkd, wvd], dim=3)                       # [C,1,1,2C]: dtok = dk Wk + dv Wv
-        dtok = hip.conv_fwd(dkv4, wkvd).view(K, P + 1, C)
         _, wqd = ap.pq.get(T, True)
         dtok[:, 0, :] += hip.conv_fwd(dq0.view(1, 1, K, C), wqd).view(K, C)
         if train:
-            hip.colsum(dtok.view(-1, C), period=P + 1, out=_grad_buf(ap.pos))
-        dx = hip.attn_tokens_bwd(dtok).view(K, h, w, C) if ctx.needs_input_grad[0] else None
+            gpos = hip.colsum(dtok.view(-1, C), period=TP)
+            _grad_buf(ap.pos).add_(gpos[:P + 1])
+        dx = hip.attn_tokens_bwd(dtok, P).view(K, h, w, C) if ctx.needs_input_grad[0] else None
         return dx, None, None
 
 

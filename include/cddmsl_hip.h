@@ -39,6 +39,13 @@ int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, c
 /* dW[n][k] (f32, accumulated) += scale[n] * sum_m dY[m][n] * im2col(x)[m][k] */
 int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const float* scale, int Nimg, int Hi, int Wi, int Cin,
                       int Cout, int KH, int KW, int stride, int pad, int pool, int ldd, int dtype, void* stream);
+/* batched GEMMs on the same kernels (strides in elements; used by the reassociated attention pool):
+ *   nt: C_b[m][n] = sum_k A_b[m][k] B_b[n][k] (+ bias[n]);   tn: out_b[n][k] (+)= sum_m A_b[m][n] B_b[m][k]
+ *   tn mode 0 = f32 atomic accumulate, 1 = f32 store, 2 = `dtype` store */
+int cddmsl_gemm_nt_batched(const void* a, const void* w, void* c, const float* bias, int M, int N, int K, int lda, int ldb, int ldc,
+                           int batch, long sa, long sw, long sc, int out_f32, int dtype, void* stream);
+int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, int M, int N, int K, int lda, int ldb, int ldo, int batch, long sa,
+                           long sb, long so, int mode, int dtype, void* stream);
 /* f32 master -> `dtype` forward weights and flipped/transposed dgrad weights scaled by the FrozenBN scale */
 int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int Cout, int KH, int KW, int Cin,
                        int dtype, void* stream);
@@ -66,13 +73,10 @@ int cddmsl_iou_match(const float* gt, int G, const float* preds, int P, long* ma
                      unsigned int* best_ws, int nthr, float t0, float t1, int l0, int l1, int l2, int allow_low_quality,
                      void* stream);
 
-/* ---- CLIP attention pool, query-0-only core  (modeling/backbone/clip_backbone.py:83-107) ---------------------- */
-int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int C, int dtype, void* stream);
-int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, int C, int dtype, void* stream);
-int cddmsl_attnpool_core_fwd(const void* q0, const void* kv, void* o, float* p, int K, int T, int H, float scale, int dtype,
-                             void* stream);
-int cddmsl_attnpool_core_bwd(const void* dO, const void* q0, const void* kv, const float* p, void* dq0, void* dkv, int K,
-                             int T, int H, float scale, int dtype, void* stream);
+/* ---- CLIP attention pool (modeling/backbone/clip_backbone.py:83-107): token build/backward; the query-0 attention itself is
+ * reassociated into the batched GEMMs above (cddmsl_amd/layers.py::AttnPoolFn) ------------------------------------- */
+int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int TP, int C, int dtype, void* stream);
+int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, int TP, int C, int dtype, void* stream);
 
 /* ---- fp32 heads: cosine-logit classifier (modeling/roi_heads/fast_rcnn.py:546-572) and the contrastive loss over
  * the cosine-similarity matrix (modeling/meta_arch/rcnn.py:308-317,458-468) ------------------------------------ */
