@@ -113,7 +113,12 @@ def main():
 
     if rank == 0:
         gb = args.batch * world
-        dom = prof.get("conv_fwd", {"flops": 0.0, "ms": 0.0, "launches": 0})
+        dom = prof.get("conv_fwd", {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
+        # HBM traffic per launch of the dominant kernel from the PMC passes (tools/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if args.batch == 16 and args.dtype == "bf16" and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("k_conv_fwd", {}).get("hbm_bytes_per_launch")
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         peak = 2500.0 if args.dtype == "bf16" else 157.3
         out = {
@@ -125,7 +130,10 @@ def main():
                                    f"{args.height}x{args.width}, synthetic pixels + seeded random weights",
                        "global_batch": gb, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "k_conv_fwd (implicit-GEMM conv/linear fwd+dgrad)", "achieved": ach,
-                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                         "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",
+                         "algorithmic_bytes_per_launch": dom.get("bytes", 0.0) / max(dom["launches"], 1),
+                         "algorithmic_flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                          "launches_per_step": dom["launches"] / max(args.steps, 1),
                          "kernel_ms_per_step": dom["ms"] / max(args.steps, 1)},
             "kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in prof.items()},

@@ -74,12 +74,12 @@ class _Profiler:
         e.record()
         return e
 
-    def end(self, e0, name, flops=0.0, shape=None):
+    def end(self, e0, name, flops=0.0, shape=None, nbytes=0.0):
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.events.append((name, flops, e0, e1))
+        self.events.append((name, flops, e0, e1, nbytes))
         if shape is not None:
             self.shapes.append((name, shape, flops, e0, e1))
 
@@ -97,9 +97,10 @@ class _Profiler:
     def collect(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1 in self.events:
-            d = out.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0})
+        for name, flops, e0, e1, nbytes in self.events:
+            d = out.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
             d["flops"] += flops
+            d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
             d["launches"] += 1
         self.on, self.events = False, []
@@ -153,7 +154,11 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
                               int(relu), int(out_f32), _dt(x), stream_ptr())
     check(st, "cddmsl_conv_fwd")
     PROFILE.end(e0, "conv_fwd", 2.0 * N * Ho * Wo * Cout * KH * KW * Cin,    # algorithmic 2*M*N*K
-                (N * Ho * Wo, Cout, KH * KW * Cin, KH, int(pool), stride))
+                (N * Ho * Wo, Cout, KH * KW * Cin, KH, int(pool), stride),
+                # algorithmic HBM bytes: every operand once
+                nbytes=float(x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()
+                             + (residual.numel() * residual.element_size() if residual is not None else 0)
+                             + (relu_mask.numel() * relu_mask.element_size() if relu_mask is not None else 0)))
     return y
 
 
