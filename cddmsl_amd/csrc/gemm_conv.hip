@@ -450,6 +450,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   const int wm = wv >> 1, wn = wv & 1;
   const int r = lane & 31, h = lane >> 5;
 
+  // Epilogue operands (residual, ReLU mask) are fetched NOW, under the whole K loop, instead of inside the epilogue where
+  // their HBM latency (~2 us per pass) was fully exposed on the small-K / wide-N layers (conv3 + residual, dgrad + mask).
+  const bool vec_ok = (p.Cout % 8 == 0) && (p.ldy % 8 == 0) && (!p.residual || p.ldr % 8 == 0) && (!p.relu_mask || p.ldm % 8 == 0);
+  constexpr bool PRE = Mma<T>::ES == 2;
+  u32x4 rres[2][4], rmsk[2][4];
+  if (PRE && vec_ok && (p.residual || p.relu_mask)) {
+    const int n = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int m = m0 + wm * 64 + a * 32 + (lane >> 3) + 8 * i;
+        bool ok = m < p.M && n < p.Cout;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        rres[a][i] = (ok && p.residual) ? *(const u32x4*)(p.residual + ((long)m * p.ldr + n) * 2) : z;
+        rmsk[a][i] = (ok && p.relu_mask) ? *(const u32x4*)(p.relu_mask + ((long)m * p.ldm + n) * 2) : z;
+      }
+  }
+
   stage(0);
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
@@ -491,7 +510,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   // (32 rows x 64 cols f32 per pass, 32-byte column groups XOR-swizzled by row) so that every lane owns
   // 8 consecutive channels of one pixel: residual / mask are read and y is written 16-32 B per lane,
   // whole 128-B lines per 8 lanes -- the scalar path issued 64 two-byte stores per lane instead.
-  const bool vec_ok = (p.Cout % 8 == 0) && (p.ldy % 8 == 0) && (!p.residual || p.ldr % 8 == 0) && (!p.relu_mask || p.ldm % 8 == 0);
   if (vec_ok) {
     float* ep = (float*)&lds[0][0][0] + wv * 2048;      // 8 KB per wave; the K-loop's last barrier already passed
     const int cg = lane & 7, rr = lane >> 3;
@@ -526,7 +544,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
           for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
           if (p.residual) {
             float rv[8];
-            load8<T>(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES, rv);
+            if (PRE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { rv[2 * j] = bf2f(rres[a][i][j] & 0xffff); rv[2 * j + 1] = bf2f(rres[a][i][j] >> 16); }
+            } else load8<T>(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES, rv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rv[j];
           }
@@ -536,7 +557,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
           }
           if (p.relu_mask) {
             float mv[8];
-            load8<T>(p.relu_mask + ((long)m * p.ldm + n) * Mma<T>::ES, mv);
+            if (PRE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { mv[2 * j] = bf2f(rmsk[a][i][j] & 0xffff); mv[2 * j + 1] = bf2f(rmsk[a][i][j] >> 16); }
+            } else load8<T>(p.relu_mask + ((long)m * p.ldm + n) * Mma<T>::ES, mv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
           }
