@@ -89,20 +89,25 @@ __global__ void k_nms_mask(const float* boxes, unsigned long long* mask, int n, 
   }
   mask[((long)img * n + i) * nw + cb] = bits;
 }
-// one wave per image: lanes hold the `removed` words (pre-seeded with the invalid boxes, so the scan loop touches
-// global memory only for boxes it keeps); scan rows in order.
-__global__ void k_nms_scan(const unsigned long long* mask, const unsigned char* valid, int* keep, int* nkeep, int n, int nw,
-                           int max_keep) {
-  int img = blockIdx.x, lane = threadIdx.x;
+// One workgroup per image.  The dependent chain of greedy NMS is resolved 64 boxes (one mask word) at a time: all four
+// waves first pull the chunk's 64 x (nw - c) mask words into LDS in parallel (one HBM latency per chunk instead of one
+// per kept box), then wave 0 walks the 64 candidates against the `removed` words it holds in registers (pre-seeded with
+// the invalid boxes) reading mask rows from LDS only.
+constexpr int NMS_MAXW = 192;   // mask words per row held in LDS: up to 12288 boxes (pre-NMS top-k is 12000)
+__global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* mask, const unsigned char* valid, int* keep,
+                                                   int* nkeep, int n, int nw, int max_keep) {
+  __shared__ unsigned long long rows[64][NMS_MAXW + 1];
+  __shared__ int s_cnt;
+  const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const unsigned long long* m = mask + (long)img * n * nw;
   const unsigned char* v = valid + (long)img * n;
-  constexpr int WPL = 8;  // words per lane -> up to 64*8*64 = 32768 boxes
+  constexpr int WPL = 3;       // words per lane of wave 0: 64*3 = 192 words
   unsigned long long removed[WPL];
 #pragma unroll
   for (int q = 0; q < WPL; ++q) {
     unsigned long long bits = 0;
     int ww = q * 64 + lane;
-    if (ww < nw) {
+    if (wv == 0 && ww < nw) {
       for (int b = 0; b < 64; ++b) {
         int i = ww * 64 + b;
         if (i >= n || v[i] != 1) bits |= 1ull << b;
@@ -110,23 +115,39 @@ __global__ void k_nms_scan(const unsigned long long* mask, const unsigned char* 
     }
     removed[q] = bits;
   }
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
   int cnt = 0;
-  for (int i = 0; i < n && cnt < max_keep; ++i) {
-    int w = i >> 6;
-    unsigned long long word = 0;
-#pragma unroll
-    for (int q = 0; q < WPL; ++q) if ((w >> 6) == q) word = removed[q];
-    word = __shfl(word, w & 63, 64);
-    if ((word >> (i & 63)) & 1ull) continue;      // uniform
-    if (lane == 0) keep[(long)img * max_keep + cnt] = i;
-    ++cnt;
-#pragma unroll
-    for (int q = 0; q < WPL; ++q) {
-      int ww = q * 64 + lane;
-      if (ww < nw && ww >= w) removed[q] |= m[(long)i * nw + ww];
+  for (int c = 0; c < nw; ++c) {
+    // cooperative load of rows 64c..64c+63, words c..nw-1
+    const int wcount = nw - c;
+    for (int idx = t; idx < 64 * wcount; idx += 256) {
+      int rr = idx / wcount, ww = c + idx % wcount;
+      int i = c * 64 + rr;
+      rows[rr][ww] = i < n ? m[(long)i * nw + ww] : 0ull;
     }
+    __syncthreads();
+    if (wv == 0) {
+      for (int b = 0; b < 64 && cnt < max_keep; ++b) {
+        unsigned long long word = 0;
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) if ((c >> 6) == q) word = removed[q];
+        word = __shfl(word, c & 63, 64);
+        if ((word >> b) & 1ull) continue;
+        if (lane == 0) keep[(long)img * max_keep + cnt] = c * 64 + b;
+        ++cnt;
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) {
+          int ww = q * 64 + lane;
+          if (ww < nw && ww >= c) removed[q] |= rows[b][ww];
+        }
+      }
+      if (lane == 0) s_cnt = cnt;
+    }
+    __syncthreads();
+    if (s_cnt >= max_keep) break;
   }
-  if (lane == 0) nkeep[img] = cnt;
+  if (t == 0) nkeep[img] = s_cnt;
 }
 
 // ---------------------------------------------------------------- fused IoU + Matcher
@@ -226,12 +247,12 @@ extern "C" int cddmsl_rpn_decode(const int* order, const float* deltas, const fl
 // keep [N][max_keep] (positions into the sorted list, score order), nkeep [N].
 extern "C" int cddmsl_nms(const float* boxes, const unsigned char* valid, unsigned long long* mask_ws, int* keep, int* nkeep,
                           int N, int n, float thr, int max_keep, void* stream) {
-  if (N <= 0 || n < 0 || max_keep <= 0 || n > 32768) return CDDMSL_ERR_ARG;
+  if (N <= 0 || n < 0 || max_keep <= 0 || n > 64 * NMS_MAXW) return CDDMSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (n == 0) return hipMemsetAsync(nkeep, 0, sizeof(int) * N, st) == hipSuccess ? CDDMSL_OK : CDDMSL_ERR_LAUNCH;
   int nw = (n + 63) / 64;
   k_nms_mask<<<dim3(nw, nw, N), dim3(64), 0, st>>>(boxes, mask_ws, n, nw, thr);
-  k_nms_scan<<<dim3(N), dim3(64), 0, st>>>(mask_ws, valid, keep, nkeep, n, nw, max_keep);
+  k_nms_scan<<<dim3(N), dim3(256), 0, st>>>(mask_ws, valid, keep, nkeep, n, nw, max_keep);
   return launch_status();
 }
 

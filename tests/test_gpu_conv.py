@@ -104,3 +104,40 @@ def test_linear_tails():
         yb = hip.linear_fwd(x.cuda().bfloat16(), w.cuda().bfloat16(), None, b.cuda(), out_f32=True)
         assert yb.dtype == torch.float32
         assert (yb.cpu() - ref).abs().max() < 3e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_batched_gemms(dtype, tol):
+    """The strided/batched NT and TN GEMM entry points used by the reassociated attention pool."""
+    from cddmsl_amd import hip
+    g = torch.Generator().manual_seed(5)
+    # NT over "heads": C[:, h*N:(h+1)*N] = A[:, h*Kd:(h+1)*Kd] @ W[h*N:(h+1)*N, :Kd]^T with strided operands
+    M, Hh, Kd, N = 70, 3, 64, 40
+    A = torch.randn(M, Hh * Kd, generator=g).to(dtype)
+    W = torch.randn(Hh * N, Kd, generator=g).to(dtype)
+    C = torch.zeros(M, Hh * N, dtype=torch.float32).cuda()
+    hip.gemm_nt_batched(A.cuda(), W.cuda(), C, M, N, Kd, Hh * Kd, Kd, Hh * N, Hh, Kd, N * Kd, N)
+    ref = torch.cat([A.float()[:, h * Kd:(h + 1) * Kd] @ W.float()[h * N:(h + 1) * N].t() for h in range(Hh)], dim=1)
+    assert (C.cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    # NT over "regions": S[b] = U[b] (32 x 128) @ T[b]^T (56 x 128)
+    B = 5
+    U = torch.randn(B, 32, 128, generator=g).to(dtype)
+    Tk = torch.randn(B, 56, 128, generator=g).to(dtype)
+    S = torch.zeros(B, 32, 56, dtype=torch.float32).cuda()
+    hip.gemm_nt_batched(U.cuda(), Tk.cuda(), S, 32, 56, 128, 128, 128, 56, B, 32 * 128, 56 * 128, 32 * 56)
+    ref = torch.bmm(U.float(), Tk.float().transpose(1, 2))
+    assert (S.cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    # TN direct store: Z[b] (32 x 128) = P[b]^T-ish: sum_m A[b][m][n] * X[b][m][k]
+    Pm = torch.randn(B, 56, 32, generator=g).to(dtype)
+    Z = torch.zeros(B, 32, 128, dtype=dtype).cuda()
+    hip.gemm_tn_batched(Pm.cuda(), Tk.cuda(), Z, 56, 32, 128, 32, 128, 128, B, 56 * 32, 56 * 128, 32 * 128)
+    ref = torch.bmm(Pm.float().transpose(1, 2), Tk.float())
+    assert (Z.float().cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    # TN accumulate (f32 atomics, many row tiles, split over blocks): dW[h] += A[:, h]^T @ X[:, h]
+    Mr = 1500
+    Ar = torch.randn(Mr, Hh * 64, generator=g).to(dtype)
+    Xr = torch.randn(Mr, Hh * 128, generator=g).to(dtype)
+    out = torch.ones(Hh * 64, 128, dtype=torch.float32).cuda()
+    hip.gemm_tn_batched(Ar.cuda(), Xr.cuda(), out, Mr, 64, 128, Hh * 64, Hh * 128, 128, Hh, 64, 128, 64 * 128, accumulate=True)
+    ref = 1.0 + torch.cat([Ar.float()[:, h * 64:(h + 1) * 64].t() @ Xr.float()[:, h * 128:(h + 1) * 128] for h in range(Hh)], dim=0)
+    assert (out.cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
