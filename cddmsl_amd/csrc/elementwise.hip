@@ -46,7 +46,7 @@ template <> struct Elt<float> {
 // ---------------------------------------------------------------- preprocess (full resolution)
 template <typename T>
 __global__ void k_preprocess(const unsigned char* img, char* out, int n, int h, int w, int Hp, int Wp, int Cp,
-                             float m0, float m1, float m2, float s0, float s1, float s2) {
+                             float m0, float m1, float m2, float s0, float s1, float s2, float div) {
   // one thread per padded output pixel of image n; out[n][y][x][0..Cp)
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)Hp * Wp) return;
@@ -54,9 +54,9 @@ __global__ void k_preprocess(const unsigned char* img, char* out, int n, int h, 
   float v[3] = {0.f, 0.f, 0.f};
   if (y < h && x < w) {
     long o = (long)y * w + x, pl = (long)h * w;
-    v[0] = ((float)img[o] / 255.0f - m0) / s0;
-    v[1] = ((float)img[pl + o] / 255.0f - m1) / s1;
-    v[2] = ((float)img[2 * pl + o] / 255.0f - m2) / s2;
+    v[0] = ((float)img[o] / div - m0) / s0;
+    v[1] = ((float)img[pl + o] / div - m1) / s1;
+    v[2] = ((float)img[2 * pl + o] / div - m2) / s2;
   }
   char* dst = out + (((long)n * Hp + y) * Wp + x) * Cp * Elt<T>::ES;
   for (int c = 0; c < Cp; ++c) Elt<T>::st(dst + c * Elt<T>::ES, c < 3 ? v[c] : 0.f);
@@ -147,6 +147,74 @@ __global__ void k_avgpool2_bwd(const char* dy, const char* mask, const char* add
     }
     ((u32x4*)dx)[i] = Elt<T>::pack(o);
   }
+}
+
+// ---------------------------------------------------------------- stock ResNet pieces (config #1: detectron2 R50-C4)
+// F.max_pool2d(x, 3, stride 2, padding 1)  (BasicStem, modeling/backbone/resnet.py:355-358), NHWC, forward only (stem frozen)
+template <typename T>
+__global__ void k_maxpool3s2(const char* x, char* y, int N, int H, int W, int Ho, int Wo, int cch) {
+  long total = (long)N * Ho * Wo * cch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cch; long q = i / cch;
+    int ox = q % Wo; q /= Wo;
+    int oy = q % Ho; int n = q / Ho;
+    float m[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+      int iy = 2 * oy - 1 + dy;
+      if (iy < 0 || iy >= H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        int ix = 2 * ox - 1 + dx;
+        if (ix < 0 || ix >= W) continue;
+        Elt<T>::unpack(((const u32x4*)x)[(((long)n * H + iy) * W + ix) * cch + c], v);
+#pragma unroll
+        for (int j = 0; j < Elt<T>::VEC; ++j) m[j] = fmaxf(m[j], v[j]);
+      }
+    }
+    ((u32x4*)y)[i] = Elt<T>::pack(m);
+  }
+}
+// backward of a stride-2 1x1 convolution's input gather: dx[n][y][x] = t[n][y/2][x/2] on even (y,x), 0 elsewhere,
+// (+ add) then masked by (mask > 0)   (BottleneckBlock conv1 / shortcut with STRIDE_IN_1X1, resnet.py:100-210)
+template <typename T>
+__global__ void k_upsample_zero2(const char* t, const char* mask, const char* add, char* dx, int N, int H, int W, int Ho, int Wo, int cch) {
+  long total = (long)N * H * W * cch;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cch; long q = i / cch;
+    int xx = q % W; q /= W;
+    int yy = q % H; int n = q / H;
+    float g[8], m[8], a[8], o[8];
+    bool in = !(yy & 1) && !(xx & 1) && (yy >> 1) < Ho && (xx >> 1) < Wo;
+    if (in) Elt<T>::unpack(((const u32x4*)t)[(((long)n * Ho + (yy >> 1)) * Wo + (xx >> 1)) * cch + c], g);
+    if (mask) Elt<T>::unpack(((const u32x4*)mask)[i], m);
+    if (add) Elt<T>::unpack(((const u32x4*)add)[i], a);
+#pragma unroll
+    for (int j = 0; j < Elt<T>::VEC; ++j) {
+      float v = in ? g[j] : 0.f;
+      if (add) v += a[j];
+      if (mask && !(m[j] > 0.f)) v = 0.f;
+      o[j] = v;
+    }
+    ((u32x4*)dx)[i] = Elt<T>::pack(o);
+  }
+}
+// x [K][P][C] -> mean over P (f32 out); backward broadcasts dy/P  (Res5ROIHeads box_features.mean(dim=[2,3]), roi_heads.py:487)
+template <typename T>
+__global__ void k_meanpool_fwd(const char* x, float* y, long K, int P, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * C) return;
+  long k = i / C; int c = i % C;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += Elt<T>::ld(x + ((k * P + p) * C + c) * Elt<T>::ES);
+  y[i] = s / (float)P;
+}
+template <typename T>
+__global__ void k_meanpool_bwd(const float* dy, char* dx, long K, int P, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * P * C) return;
+  int c = i % C; long k = i / ((long)P * C);
+  Elt<T>::st(dx + i * Elt<T>::ES, dy[k * C + c] / (float)P);
 }
 
 // ---------------------------------------------------------------- attention-pool tokens
@@ -272,12 +340,12 @@ inline unsigned gsz(long n, int per = 256, long cap = 8192) {
   } while (0)
 
 extern "C" int cddmsl_preprocess(const unsigned char* img, void* out, int n, int h, int w, int Hp, int Wp, int Cp,
-                                 const float* mean3, const float* std3, int dtype, void* stream) {
+                                 const float* mean3, const float* std3, int div255, int dtype, void* stream) {
   if (h <= 0 || w <= 0 || h > Hp || w > Wp || Cp < 3) return CDDMSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   long px = (long)Hp * Wp;
   DISPATCH(dtype, k_preprocess, <<<dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st>>>(
-      img, (char*)out, n, h, w, Hp, Wp, Cp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]));
+      img, (char*)out, n, h, w, Hp, Wp, Cp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], div255 ? 255.0f : 1.0f));
   return launch_status();
 }
 
@@ -311,6 +379,41 @@ extern "C" int cddmsl_avgpool2_bwd(const void* dy, const void* mask, const void*
   if (total == 0) return CDDMSL_OK;
   DISPATCH(dtype, k_avgpool2_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>(
       (const char*)dy, (const char*)mask, (const char*)add, (char*)dx, N, H, W, cch));
+  return launch_status();
+}
+
+extern "C" int cddmsl_maxpool3s2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((C * es) % 16 || H < 1 || W < 1) return CDDMSL_ERR_ARG;
+  int cch = C * es / 16, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  long total = (long)N * Ho * Wo * cch;
+  if (total == 0) return CDDMSL_OK;
+  DISPATCH(dtype, k_maxpool3s2, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)x, (char*)y, N, H, W, Ho, Wo, cch));
+  return launch_status();
+}
+extern "C" int cddmsl_upsample_zero2(const void* t, const void* mask, const void* add, void* dx, int N, int H, int W, int C,
+                                     int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((C * es) % 16 || H < 1 || W < 1) return CDDMSL_ERR_ARG;
+  int cch = C * es / 16, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  long total = (long)N * H * W * cch;
+  if (total == 0) return CDDMSL_OK;
+  DISPATCH(dtype, k_upsample_zero2, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>(
+      (const char*)t, (const char*)mask, (const char*)add, (char*)dx, N, H, W, Ho, Wo, cch));
+  return launch_status();
+}
+extern "C" int cddmsl_meanpool_fwd(const void* x, float* y, long K, int P, int C, int dtype, void* stream) {
+  if (K < 0 || P <= 0 || C <= 0) return CDDMSL_ERR_ARG;
+  if (K == 0) return CDDMSL_OK;
+  long n = K * C;
+  DISPATCH(dtype, k_meanpool_fwd, <<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>((const char*)x, y, K, P, C));
+  return launch_status();
+}
+extern "C" int cddmsl_meanpool_bwd(const float* dy, void* dx, long K, int P, int C, int dtype, void* stream) {
+  if (K < 0 || P <= 0 || C <= 0) return CDDMSL_ERR_ARG;
+  if (K == 0) return CDDMSL_OK;
+  long n = K * P * C;
+  DISPATCH(dtype, k_meanpool_bwd, <<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(dy, (char*)dx, K, P, C));
   return launch_status();
 }
 

@@ -23,7 +23,11 @@ def _L():
         L.cddmsl_conv_fwd.argtypes = [vp] * 7 + [ci] * 16 + [vp]
         L.cddmsl_conv_wgrad.argtypes = [vp] * 4 + [ci] * 12 + [vp]
         L.cddmsl_weight_prep.argtypes = [vp] * 4 + [ci] * 5 + [vp]
-        L.cddmsl_preprocess.argtypes = [vp, vp] + [ci] * 6 + [vp, vp, ci, vp]
+        L.cddmsl_preprocess.argtypes = [vp, vp] + [ci] * 6 + [vp, vp, ci, ci, vp]
+        L.cddmsl_maxpool3s2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
+        L.cddmsl_upsample_zero2.argtypes = [vp] * 4 + [ci] * 5 + [vp]
+        L.cddmsl_meanpool_fwd.argtypes = [vp, vp, c_long, ci, ci, ci, vp]
+        L.cddmsl_meanpool_bwd.argtypes = [vp, vp, c_long, ci, ci, ci, vp]
         L.cddmsl_preprocess224.argtypes = [vp, vp] + [ci] * 11 + [vp, vp, ci, vp]
         L.cddmsl_avgpool2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
         L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
@@ -210,15 +214,16 @@ def _f3(v):
 
 
 @_timed("preprocess")
-def preprocess(images_u8, Hp, Wp, mean, std, dtype, Cp=None):
-    """list of u8 CHW device tensors -> normalised, zero-padded NHWC [N,Hp,Wp,Cp] (rcnn.py:758-768)."""
+def preprocess(images_u8, Hp, Wp, mean, std, dtype, Cp=None, div255=True):
+    """list of u8 CHW device tensors -> normalised, zero-padded NHWC [N,Hp,Wp,Cp] (rcnn.py:758-768).
+    div255: CLIP models take x/255 (rcnn.py:87-91); stock models normalise raw 0-255 pixels."""
     require_cuda(*images_u8)
     Cp = Cp or (8 if dtype == torch.bfloat16 else 4)
     out = torch.empty((len(images_u8), Hp, Wp, Cp), device=images_u8[0].device, dtype=dtype)
     m, s = _f3(mean), _f3(std)
     for n, im in enumerate(images_u8):
         assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 and im.is_contiguous()
-        check(_L().cddmsl_preprocess(ptr(im), ptr(out), n, im.shape[1], im.shape[2], Hp, Wp, Cp, m, s, DT[dtype], stream_ptr()),
+        check(_L().cddmsl_preprocess(ptr(im), ptr(out), n, im.shape[1], im.shape[2], Hp, Wp, Cp, m, s, int(div255), DT[dtype], stream_ptr()),
               "cddmsl_preprocess")
     return out
 
@@ -587,3 +592,39 @@ def focal_ce_bwd(logits, target, probs, gscale, gamma, bg_class, bg_weight):
     check(_L().cddmsl_focal_ce_bwd(ptr(logits), ptr(target), ptr(probs), ptr(gscale.reshape(1).float().contiguous()), ptr(d), logits.shape[0],
                                    logits.shape[1], gamma, bg_class, bg_weight, stream_ptr()), "cddmsl_focal_ce_bwd")
     return d
+
+
+def maxpool3s2_fwd(x):
+    """F.max_pool2d(x, 3, 2, 1) on NHWC"""
+    require_cuda(x)
+    N, H, W, C = x.shape
+    y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), device=x.device, dtype=x.dtype)
+    check(_L().cddmsl_maxpool3s2_fwd(ptr(x), ptr(y), N, H, W, C, _dt(x), stream_ptr()), "cddmsl_maxpool3s2_fwd")
+    return y
+
+
+def upsample_zero2(t, in_shape, mask=None, add=None):
+    """dx[:, ::2, ::2] = t, zero elsewhere (+ add), zeroed where mask <= 0: input gradient of a stride-2 1x1 conv."""
+    require_cuda(t, mask, add)
+    N, H, W, C = in_shape
+    assert t.is_contiguous() and tuple(t.shape) == (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C)
+    dx = torch.empty(in_shape, device=t.device, dtype=t.dtype)
+    check(_L().cddmsl_upsample_zero2(ptr(t), ptr(mask), ptr(add), ptr(dx), N, H, W, C, _dt(t), stream_ptr()), "cddmsl_upsample_zero2")
+    return dx
+
+
+def meanpool_fwd(x):
+    """x [K,P,C] (T) -> [K,C] f32"""
+    require_cuda(x)
+    K, P, C = x.shape
+    y = torch.empty((K, C), device=x.device, dtype=torch.float32)
+    check(_L().cddmsl_meanpool_fwd(ptr(x), ptr(y), K, P, C, _dt(x), stream_ptr()), "cddmsl_meanpool_fwd")
+    return y
+
+
+def meanpool_bwd(dy, P, dtype):
+    require_cuda(dy)
+    K, C = dy.shape
+    dx = torch.empty((K, P, C), device=dy.device, dtype=dtype)
+    check(_L().cddmsl_meanpool_bwd(ptr(dy.contiguous().float()), ptr(dx), K, P, C, DT[dtype], stream_ptr()), "cddmsl_meanpool_bwd")
+    return dx

@@ -20,10 +20,20 @@ def bump_weight_version():
     _STEP[0] += 1
 
 
+_TOUCHED = set()   # ids of parameters that received a gradient this step (SGD skips grad-less parameters)
+
+
 def _grad_buf(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+    _TOUCHED.add(id(p))
     return p.grad
+
+
+def take_touched():
+    t = set(_TOUCHED)
+    _TOUCHED.clear()
+    return t
 
 
 def _ohwi(w):
@@ -495,3 +505,22 @@ class FocalCEFn(torch.autograd.Function):
 
 def focal_cross_entropy(logits, target, gamma, bg_class, bg_weight):
     return FocalCEFn.apply(logits, target, float(gamma or 0.0), int(bg_class), float(1.0 if bg_weight is None else bg_weight))
+
+
+class MeanPoolFn(torch.autograd.Function):
+    """box_features.mean(dim=[2, 3]) of Res5ROIHeads (roi_heads.py:487): [K,h,w,C] T -> [K,C] f32"""
+
+    @staticmethod
+    def forward(ctx, x):
+        K, h, w, C = x.shape
+        ctx.meta = (K, h, w, C, x.dtype)
+        return hip.meanpool_fwd(x.contiguous().view(K, h * w, C))
+
+    @staticmethod
+    def backward(ctx, dy):
+        K, h, w, C, T = ctx.meta
+        return hip.meanpool_bwd(dy, h * w, T).view(K, h, w, C)
+
+
+def mean_pool(x_nhwc):
+    return MeanPoolFn.apply(x_nhwc)

@@ -16,6 +16,7 @@ from torch import nn
 from .. import hip, layers
 from ..registry import META_ARCH_REGISTRY
 from ..structures import ImageList, as_instances
+from . import resnet  # noqa: F401  (registers build_resnet_backbone)
 from .backbone import build_backbone, to_nchw
 from .clipcap import v2l
 from .roi_heads import build_roi_heads
@@ -61,8 +62,8 @@ class GeneralizedRCNN(nn.Module):
         self.offline_backbone = build_backbone(cfg)
         for p in self.offline_backbone.parameters():
             p.requires_grad = False
-        for st in (self.offline_backbone.layer1, self.offline_backbone.layer2, self.offline_backbone.layer3, self.offline_backbone.layer4):
-            for blk in st:
+        for blk in self.offline_backbone.modules():
+            if hasattr(blk, "frozen"):
                 blk.frozen = True
         self.offline_backbone.eval()
         self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
@@ -71,8 +72,8 @@ class GeneralizedRCNN(nn.Module):
         self.pixel_mean_list, self.pixel_std_list = list(cfg.MODEL.PIXEL_MEAN), list(cfg.MODEL.PIXEL_STD)
         self.register_buffer("pixel_mean", torch.tensor(self.pixel_mean_list).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(self.pixel_std_list).view(-1, 1, 1), False)
-        assert sum(self.pixel_mean_list) < 3.0 and self.input_format == "RGB", "CLIP models take RGB/255 inputs (rcnn.py:87-91)"
-        self.div_pixel = True
+        self.div_pixel = sum(self.pixel_mean_list) < 3.0      # CLIP models take RGB/255 inputs (rcnn.py:87-91)
+        assert not self.div_pixel or self.input_format == "RGB"
         self.use_clip_c4 = cfg.MODEL.BACKBONE.NAME == "build_clip_resnet_backbone"
         self.use_clip_attpool = cfg.MODEL.ROI_HEADS.NAME == "CLIPRes5ROIHeads" and cfg.MODEL.CLIP.USE_TEXT_EMB_CLASSIFIER
         self.projector = nn.Sequential(_Linear(768, 768), nn.ReLU(), _Linear(768, 256))   # rcnn.py:95-99
@@ -93,7 +94,7 @@ class GeneralizedRCNN(nn.Module):
         imgs = self._images(batched_inputs, key)
         sizes = [tuple(i.shape[-2:]) for i in imgs]
         Hp, Wp = max(s[0] for s in sizes), max(s[1] for s in sizes)
-        return hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype), sizes
+        return hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype, div255=self.div_pixel), sizes
 
     def preprocess_image_train(self, batched_inputs):
         """rcnn.py:161-179 -> NHWC [2N,224,224,Cp]: rows [0,N) = source images, [N,2N) = target images.
@@ -162,8 +163,11 @@ class GeneralizedRCNN(nn.Module):
         gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]
         res4 = self.backbone.forward_nhwc(images, want_res5=False)["res4"]
         proposals, proposal_losses = self.proposal_generator.forward_nhwc(sizes, res4, gts)
-        _, detector_losses = self.roi_heads(ImageList(None, sizes), {"res4": to_nchw(res4)}, proposals, gts,
-                                            res5=self.backbone.layer4, attnpool=self.backbone.attnpool)
+        if self.use_clip_c4:    # C4 + CLIP weights: the head borrows the backbone's layer4 / attnpool (rcnn.py:606-612)
+            _, detector_losses = self.roi_heads(ImageList(None, sizes), {"res4": to_nchw(res4)}, proposals, gts,
+                                                res5=self.backbone.layer4, attnpool=self.backbone.attnpool)
+        else:                   # default setting (rcnn.py:613-614)
+            _, detector_losses = self.roi_heads(ImageList(None, sizes), {"res4": to_nchw(res4)}, proposals, gts)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)

@@ -61,18 +61,23 @@ class FastRCNNOutputLayers(nn.Module):
     def __init__(self, cfg, input_shape):
         super().__init__()
         c = cfg.MODEL.CLIP
-        assert c.USE_TEXT_EMB_CLASSIFIER, "only the CLIP text-embedding classifier is on the hot path"
         self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
-        d = c.TEXT_EMB_DIM
-        self.temperature = c.CLSS_TEMP
-        self.cls_score = _Linear(d, self.num_classes, bias=False)
-        self.cls_bg_score = _Linear(d, 1, bias=False)
-        nn.init.normal_(self.cls_score.weight, std=0.01)
-        nn.init.constant_(self.cls_bg_score.weight, 0)
-        if c.TEXT_EMB_PATH:
-            self.cls_score.weight.data.copy_(torch.load(c.TEXT_EMB_PATH, map_location="cpu", weights_only=True))
-        self.cls_score.weight.requires_grad = False       # frozen embeddings fast_rcnn.py:453
-        self.cls_bg_score.weight.requires_grad = False    # zero background embedding :458-463
+        self.use_clip_cls_emb = bool(c.USE_TEXT_EMB_CLASSIFIER)
+        if self.use_clip_cls_emb:       # CLIP text embeddings as the classifier (fast_rcnn.py:440-475)
+            d = c.TEXT_EMB_DIM
+            self.temperature = c.CLSS_TEMP
+            self.cls_score = _Linear(d, self.num_classes, bias=False)
+            self.cls_bg_score = _Linear(d, 1, bias=False)
+            nn.init.normal_(self.cls_score.weight, std=0.01)
+            nn.init.constant_(self.cls_bg_score.weight, 0)
+            if c.TEXT_EMB_PATH:
+                self.cls_score.weight.data.copy_(torch.load(c.TEXT_EMB_PATH, map_location="cpu", weights_only=True))
+            self.cls_score.weight.requires_grad = False       # frozen embeddings fast_rcnn.py:453
+            self.cls_bg_score.weight.requires_grad = False    # zero background embedding :458-463
+        else:                           # regular linear classifier (fast_rcnn.py:476-479), stock R50-C4
+            d = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+            self.cls_score = _Linear(d, self.num_classes + 1)
+            nn.init.normal_(self.cls_score.weight, std=0.01)
         self.bbox_pred = _Linear(d, self.num_classes * 4)
         nn.init.normal_(self.bbox_pred.weight, std=0.001)
         self.box_weights = tuple(cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS)
@@ -93,9 +98,17 @@ class FastRCNNOutputLayers(nn.Module):
 
     def forward(self, x):
         """x [R, 1024] f32 -> (scores [R, K+1] f32, deltas [R, 4K] f32)   fast_rcnn.py:529-572"""
-        scores = layers.cosine_logits(x, self._text_emb(), self.temperature)
-        deltas = layers.linear(x.to(self.compute_dtype), self.bbox_pred.pw(), self.bbox_pred.bias, out_f32=True)
-        return scores, deltas
+        xt = x.to(self.compute_dtype)
+        if self.use_clip_cls_emb:
+            scores = layers.cosine_logits(x, self._text_emb(), self.temperature)
+            deltas = layers.linear(xt, self.bbox_pred.pw(), self.bbox_pred.bias, out_f32=True)
+            return scores, deltas
+        # plain classifier: cls_score (K+1) and bbox_pred (4K) as ONE padded GEMM (row widths must be whole 16-B chunks)
+        k1 = self.num_classes + 1
+        y = layers.fused_heads(xt.contiguous().view(1, 1, xt.shape[0], xt.shape[1]),
+                               [(self.cls_score.weight, self.cls_score.bias), (self.bbox_pred.weight, self.bbox_pred.bias)])
+        y = y.view(xt.shape[0], -1)
+        return y[:, :k1].contiguous(), y[:, k1:k1 + 4 * self.num_classes].contiguous()
 
     def losses(self, predictions, proposals):
         """fast_rcnn.py:574-689"""
@@ -140,7 +153,7 @@ class CLIPRes5ROIHeads(nn.Module):
         self.pooler = ROIPooler(b.POOLER_RESOLUTION, (1.0 / input_shape[self.in_features[0]].stride,),
                                 b.POOLER_SAMPLING_RATIO, b.POOLER_TYPE)
         out_channels = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS * 8
-        self.box_predictor = FastRCNNOutputLayers(cfg, ShapeSpec(channels=out_channels, height=1, width=1))
+        self.box_predictor = FastRCNNOutputLayers(cfg, ShapeSpec(channels=out_channels, height=1, width=1))   # clip_roi_heads.py:104-107
         self.sample_generator = torch.Generator()
         self.storage = {}
 
@@ -212,6 +225,26 @@ class CLIPRes5ROIHeads(nn.Module):
         att = attnpool(to_nchw(box_features))
         predictions = self.box_predictor(att)
         return [], self.box_predictor.losses(predictions, proposals)
+
+
+@ROI_HEADS_REGISTRY.register()
+class Res5ROIHeads(CLIPRes5ROIHeads):
+    """Stock C4 head (roi_heads.py:358-512): RoIAlign -> own ``res5`` stage (stride 2) -> mean pool -> linear classifier."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__(cfg, input_shape)
+        from .resnet import make_stage
+        r = cfg.MODEL.RESNETS
+        out_channels = r.RES2_OUT_CHANNELS * 8
+        self.res5 = make_stage(3, [2, 1, 1], out_channels // 2, r.get("WIDTH_PER_GROUP", 64) * 8, out_channels)   # _build_res5_block :440-463
+
+    def forward(self, images, features, proposals, targets=None, res5=None, attnpool=None):
+        assert self.training and targets
+        targets = [as_instances(t) for t in targets]
+        proposals = self.label_and_sample_proposals(proposals, targets)
+        x = self.pooler.forward_nhwc(to_nhwc(features[self.in_features[0]]), [p.proposal_boxes for p in proposals])
+        feats = layers.mean_pool(self.res5.forward_nhwc(x))
+        return [], self.box_predictor.losses(self.box_predictor(feats), proposals)
 
 
 def build_roi_heads(cfg, input_shape):

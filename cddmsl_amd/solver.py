@@ -40,7 +40,8 @@ class ClippedSGD:
                 p.grad.zero_()
 
     def step(self):
-        ps = [p for p in self.params if p.grad is not None]
+        touched = layers.take_touched()     # torch.optim.SGD skips parameters whose grad is None (e.g. the projector in stock configs)
+        ps = [p for p in self.params if p.grad is not None and id(p) in touched]
         if self.moms is None:
             self.moms = {id(p): torch.zeros_like(p, memory_format=torch.preserve_format) for p in self.params}
             self.norm_ws = torch.zeros(len(self.params), device=self.params[0].device, dtype=torch.float32)

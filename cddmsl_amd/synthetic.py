@@ -86,6 +86,45 @@ def make_state_dict(seed=0, num_classes=20, layers=RN50_LAYERS, width=64, embed_
     return sd
 
 
+def make_state_dict_r50(seed=0, num_classes=20, num_anchors=15) -> Dict[str, torch.Tensor]:
+    """Stock Detectron2 R50-C4 Faster R-CNN state dict (reference key names: ``backbone.stem.conv1.norm.weight``,
+    ``backbone.res3.0.shortcut.weight``, ``roi_heads.res5.2.conv3.weight``, ``roi_heads.box_predictor.cls_score.bias``)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(p, cout, cin, k, gain=2.0, wlo=0.8, whi=1.2):
+        sd[p + ".weight"] = _conv(g, cout, cin, k, gain)
+        _bn(sd, g, p + ".norm", cout, wlo, whi)
+
+    conv("backbone.stem.conv1", 64, 3, 7)
+    sd["backbone.stem.conv1.weight"] *= 1.0 / 64.0     # inputs are raw 0-255 pixels (mean-subtracted, std 1): keep activations O(1)
+    inc = 64
+    for name, nb, bott, outc in (("backbone.res2", 3, 64, 256), ("backbone.res3", 4, 128, 512), ("backbone.res4", 6, 256, 1024),
+                                 ("roi_heads.res5", 3, 512, 2048)):
+        for b in range(nb):
+            q = f"{name}.{b}"
+            if inc != outc:
+                conv(q + ".shortcut", outc, inc, 1, gain=1.0)
+            conv(q + ".conv1", bott, inc, 1)
+            conv(q + ".conv2", bott, bott, 3)
+            conv(q + ".conv3", outc, bott, 1, wlo=0.2, whi=0.4)
+            inc = outc
+    c4 = 1024
+    r = "proposal_generator.rpn_head"
+    sd[r + ".conv.weight"] = _conv(g, c4, c4, 3)
+    sd[r + ".conv.bias"] = torch.randn(c4, generator=g) * 0.02
+    sd[r + ".objectness_logits.weight"] = torch.randn(num_anchors, c4, 1, 1, generator=g) * (2.0 / c4) ** 0.5
+    sd[r + ".objectness_logits.bias"] = torch.randn(num_anchors, generator=g) * 0.02
+    sd[r + ".anchor_deltas.weight"] = torch.randn(num_anchors * 4, c4, 1, 1, generator=g) * 0.25 * (2.0 / c4) ** 0.5
+    sd[r + ".anchor_deltas.bias"] = torch.randn(num_anchors * 4, generator=g) * 0.02
+    b = "roi_heads.box_predictor"
+    sd[b + ".cls_score.weight"] = torch.randn(num_classes + 1, 2048, generator=g) * 2048 ** -0.5
+    sd[b + ".cls_score.bias"] = torch.randn(num_classes + 1, generator=g) * 0.02
+    sd[b + ".bbox_pred.weight"] = torch.randn(num_classes * 4, 2048, generator=g) * 0.5 * 2048 ** -0.5
+    sd[b + ".bbox_pred.bias"] = torch.zeros(num_classes * 4)
+    return sd
+
+
 def make_mapper_state_dict(seed=1, dim_clip=1024, dim=768, length=40, layers=8, std=0.02) -> Dict[str, torch.Tensor]:
     """``clip_project.*`` (TransformerMapper) state dict, keys without the ``clip_project.`` prefix."""
     g = torch.Generator().manual_seed(seed)

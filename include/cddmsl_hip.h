@@ -103,12 +103,19 @@ int cddmsl_contrastive_bwd(const float* S, const float* rlse, const float* clse,
 /* ---- elementwise: preprocessing (modeling/meta_arch/rcnn.py:161-179,758-768, structures/image_list.py:72-124),
  * AvgPool2d(2) (clip_backbone.py:36,46,147), ReLU backward, column sums, fused clip+SGD (solver/build.py:59-130) -- */
 int cddmsl_preprocess(const unsigned char* img, void* out, int n, int h, int w, int Hp, int Wp, int Cp, const float* mean3,
-                      const float* std3, int dtype, void* stream);
+                      const float* std3, int div255, int dtype, void* stream);
 int cddmsl_preprocess224(const unsigned char* img, void* out, int n, int h, int w, int Hp, int Wp, int RH, int RW, int top,
                          int left, int S, int Cp, const float* mean3, const float* std3, int dtype, void* stream);
 int cddmsl_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 int cddmsl_avgpool2_bwd(const void* dy, const void* mask, const void* add, void* dx, int N, int H, int W, int C, int dtype,
                         void* stream);
+/* stock Detectron2 R50-C4 pieces (config #1): BasicStem max-pool (modeling/backbone/resnet.py:355-358), the input-gradient
+ * scatter of stride-2 1x1 convs (STRIDE_IN_1X1 bottlenecks, resnet.py:100-210), Res5ROIHeads mean pool (roi_heads.py:487) */
+int cddmsl_maxpool3s2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int cddmsl_upsample_zero2(const void* t, const void* mask, const void* add, void* dx, int N, int H, int W, int C, int dtype,
+                          void* stream);
+int cddmsl_meanpool_fwd(const void* x, float* y, long K, int P, int C, int dtype, void* stream);
+int cddmsl_meanpool_bwd(const float* dy, void* dx, long K, int P, int C, int dtype, void* stream);
 int cddmsl_relu_bwd(const void* g, const void* y, void* dx, long numel, int g_f32, int dtype, void* stream);
 int cddmsl_colsum(const void* x, float* out, long rows, int cols, int period, int dtype, void* stream);
 int cddmsl_sgd_clip_step(float** params, const float** grads, float** moms, const long* sizes, int count, float* norm_ws,

@@ -96,3 +96,18 @@ def test_state_dict_keys_match_reference_names():
     mp = TransformerMapper()
     mp.load_state_dict(synthetic.make_mapper_state_dict(1))
     assert sum(p.numel() for p in mp.parameters()) == 69316608                      # 69.32 M frozen mapper params
+
+
+def test_stock_r50_state_dict_keys():
+    """configs[0]: stock Detectron2 R50-C4 names (stem.conv1.norm.*, res3.0.shortcut.*, roi_heads.res5.*) load into the product."""
+    from cddmsl_amd import synthetic
+    from cddmsl_amd.config import get_cfg
+    from cddmsl_amd.modeling.rcnn import GeneralizedRCNN
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "PascalVOC-Detection", "faster_rcnn_R_50_C4.yaml"))
+    m = GeneralizedRCNN(cfg)
+    missing, unexpected = m.load_state_dict(synthetic.make_state_dict_r50(0), strict=False)
+    assert not unexpected and all(k.startswith(("offline_backbone.", "projector.")) for k in missing)
+    frozen = [n for n, p in m.backbone.named_parameters() if not p.requires_grad]
+    assert any(n.startswith("stem.") for n in frozen) and any(n.startswith("res2.") for n in frozen)
+    assert all(p.requires_grad for n, p in m.backbone.named_parameters() if n.startswith(("res3.", "res4.")))

@@ -101,3 +101,47 @@ def test_bf16_step_runs_and_is_close():
     assert all(v == v and abs(v) < 1e4 for v in vals.values()), vals
     assert not torch.equal(before, model.backbone.layer3[0].conv1.weight.detach())
     tr.run_step()
+
+
+def test_stock_r50_c4_config1_matches_oracle():
+    """BASELINE.json configs[0]: configs/PascalVOC-Detection/faster_rcnn_R_50_C4.yaml, 2 synthetic images, supervised step
+    (stock ResNet-50 backbone, Res5ROIHeads mean pool, linear classifier) -- HIP path (f32) vs the CPU oracle."""
+    from cddmsl_amd import synthetic
+    from cddmsl_amd.config import get_cfg
+    from cddmsl_amd.modeling import build_model
+    from oracle import model_r50 as r50
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "PascalVOC-Detection", "faster_rcnn_R_50_C4.yaml"))
+    cfg.merge_from_list(["MODEL.COMPUTE_DTYPE", "f32", "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 48, "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 600,
+                         "MODEL.RPN.POST_NMS_TOPK_TRAIN", 200])
+    assert cfg.MODEL.BACKBONE.NAME == "build_resnet_backbone" and cfg.MODEL.ROI_HEADS.NAME == "Res5ROIHeads"
+    sd = synthetic.make_state_dict_r50(0)
+    model = build_model(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith(("offline_backbone.", "projector.")) for m in missing), (missing, unexpected)
+    g = torch.Generator().manual_seed(9)
+    model.proposal_generator.sample_generator = g
+    model.roi_heads.sample_generator = g
+    model.train()
+    batch = synthetic.make_batch(2, 160, 224, num_gt=3)
+    ld = model(batch)
+    sum(ld.values()).backward()
+    got = {k: float(v) for k, v in ld.items()}
+
+    ocfg = r50.cfg_r50()
+    ocfg.roi_batch_per_image, ocfg.rpn_pre_nms_topk, ocfg.rpn_post_nms_topk = 48, 600, 200
+    keys = r50.trainable_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    ref = r50.forward(sd, ocfg, batch, torch.Generator().manual_seed(9))
+    sum(ref.values()).backward()
+    for k, v in ref.items():
+        assert abs(got[k] - float(v)) <= 1e-3 * abs(float(v)) + 1e-6, (k, got[k], float(v))
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for k in keys:
+        gk, rk = params[k].grad.detach().float().cpu(), sd[k].grad
+        err = float((gk - rk).abs().max() / max(float(rk.abs().max()), 1e-5))
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err)
+    print("stock R50-C4 losses", got, "worst grad rel err", worst)
