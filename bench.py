@@ -128,7 +128,8 @@ def main():
             "config": {"workload": "faster_rcnn_voc.sh VOC(labeled)+Clipart(unlabeled) CLIP RN50-C4 + caption consistency "
                                    f"(iter>10000: supervised + image-level + region-level), {args.batch} img/GPU "
                                    f"{args.height}x{args.width}, synthetic pixels + seeded random weights",
-                       "global_batch": gb, "parallelism": f"dp{world}"},
+                       "global_batch": gb, "parallelism": f"dp{world}",
+                       "shared_source_pass": bool(tr.share_source_pass)},
             "roofline": {"bound": "mfma", "kernel": "k_conv_fwd (implicit-GEMM conv/linear fwd+dgrad)", "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",

@@ -97,10 +97,15 @@ class SimpleTrainer:
         self.burn_in = 10000            # train_loop.py:334
         self.metrics_period = metrics_period
         self.storage = {}
+        # run_step below issues every forward of a step before its single backward, on one batch object: the model may
+        # evaluate backbone+RPN on the source images once for the supervised and the region-level branch (rcnn.py notes)
+        self.share_source_pass = os.environ.get("CDDMSL_SHARE_SOURCE_PASS", "1") != "0"
 
     def compute_losses(self, data):
         """train_loop.py:331-365"""
         kd = self.cfg.MODEL.KD_REGULRAZIATION
+        if hasattr(self.model, "share_source_pass"):
+            self.model.share_source_pass = self.share_source_pass and self.iter > self.burn_in
         loss_dict = self.model(data)
         loss = {}
         if self.iter > self.burn_in:

@@ -80,6 +80,16 @@ class GeneralizedRCNN(nn.Module):
         self.compute_dtype = self.backbone.compute_dtype
         self.regions_per_image = 16                                                        # rcnn.py:437
         self.region_generator = torch.Generator()
+        # Within one training step the reference evaluates backbone(res1-4) + RPN on the SAME source images twice, once in
+        # the supervised forward and once in the region-level branch (rcnn.py:424-425,434 vs :597-599; identical
+        # preprocessing :201 vs :764).  Both evaluations give identical tensors, so the second is elided: the region-level
+        # branch reuses the supervised pass's res4 (gradients of both branches then flow through the one graph -- the same sum)
+        # and its RPN proposals, and still consumes the second RPN pass's random draws.  Valid only for the same batch
+        # object and the same weights (optimizer step counter), and only when all forwards of a step precede its one backward
+        # (the reference's run_step) -- so it is off on a bare model and switched on by SimpleTrainer, which guarantees that
+        # order (CDDMSL_SHARE_SOURCE_PASS=0 keeps it off there too).
+        self.share_source_pass = False
+        self._shared = None
 
     @property
     def device(self):
@@ -143,15 +153,23 @@ class GeneralizedRCNN(nn.Module):
             # source and target images stacked on the batch axis: one backbone pass over 2N images, one RoI pass over
             # 2x16N regions (identical per-sample results, half the kernel launches)
             n = len(batched_inputs)
-            imgs = self._images(batched_inputs, "image") + self._images(batched_inputs, "image_trgt")
-            sizes = [tuple(i.shape[-2:]) for i in imgs[:n]]
-            assert sizes == [tuple(i.shape[-2:]) for i in imgs[n:]], "a sample and its domain twin share one geometry"
+            shared, self._shared = self._shared, None
+            if shared is not None and not (shared["inputs"] is batched_inputs and shared["step"] == layers._STEP[0]):
+                shared = None
+            imgs = ([] if shared else self._images(batched_inputs, "image")) + self._images(batched_inputs, "image_trgt")
+            sizes = [tuple(i.shape[-2:]) for i in self._images(batched_inputs, "image")] if shared is None else shared["sizes"]
+            assert sizes == [tuple(i.shape[-2:]) for i in imgs[-n:]], "a sample and its domain twin share one geometry"
             Hp, Wp = max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes)
-            both = hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype)
-            f = self.backbone.forward_nhwc(both, want_res5=False)["res4"]
-            gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]
+            x = hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype)   # always /255: rcnn.py:201
+            f = self.backbone.forward_nhwc(x, want_res5=False)["res4"]
+            gts = [as_instances(x_["instances"]).to(self.device) for x_ in batched_inputs]
             with torch.no_grad():
-                props, _ = self.proposal_generator.forward_nhwc(sizes, f[:n].detach(), gts)
+                if shared is None:
+                    props, _ = self.proposal_generator.forward_nhwc(sizes, f[:n].detach(), gts)
+                else:
+                    f = torch.cat([shared["res4"], f])
+                    self.proposal_generator.replay_sampling_draws(shared["counts"])
+                    props = shared["proposals"]
                 sel = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image].to(self.device) for p in props]
                 props = [p[s] for p, s in zip(props, sel)]
             rs, rt = self.roi_heads.forward_get_features_paired(f, n, props, self.backbone.layer4, self.backbone.attnpool)
@@ -163,6 +181,10 @@ class GeneralizedRCNN(nn.Module):
         gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]
         res4 = self.backbone.forward_nhwc(images, want_res5=False)["res4"]
         proposals, proposal_losses = self.proposal_generator.forward_nhwc(sizes, res4, gts)
+        self._shared = None
+        if self.share_source_pass and self.use_clip_c4 and self.div_pixel:
+            self._shared = {"inputs": batched_inputs, "step": layers._STEP[0], "res4": res4, "sizes": sizes,
+                            "proposals": proposals, "counts": list(self.proposal_generator.last_counts)}
         if self.use_clip_c4:    # C4 + CLIP weights: the head borrows the backbone's layer4 / attnpool (rcnn.py:606-612)
             _, detector_losses = self.roi_heads(ImageList(None, sizes), {"res4": to_nchw(res4)}, proposals, gts,
                                                 res5=self.backbone.layer4, attnpool=self.backbone.attnpool)

@@ -44,7 +44,7 @@ def subsample_labels(labels, num_samples, positive_fraction, bg_label, gen):
     return positive[perm1], negative[perm2]
 
 
-def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_label, gen):
+def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_label, gen, counts_out=None):
     """``subsample_labels`` for a list of per-image label vectors with TWO device->host syncs in total instead of two per
     image: one nonzero over the concatenated positives, one over the negatives; the per-image permutations are then drawn
     on the host in the reference's order (image by image: positives, negatives -- sampling.py:47-48)."""
@@ -61,6 +61,8 @@ def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_labe
         p0, p1 = int(cnt[0, i]), int(cnt[0, i + 1])
         n0, n1 = int(cnt[1, i]), int(cnt[1, i + 1])
         npos, nneg = p1 - p0, n1 - n0
+        if counts_out is not None:
+            counts_out.append((npos, nneg))
         num_pos = min(npos, int(num_samples * positive_fraction))
         num_neg = min(nneg, num_samples - num_pos)
         perm1 = torch.randperm(npos, generator=gen)[:num_pos]
@@ -192,12 +194,22 @@ class RPN(nn.Module):
             idx, lab = hip.iou_match(gtb, anchors, self.iou_thresholds, self.iou_labels, True)
             labels.append(lab)
             matched.append(torch.zeros_like(anchors) if len(gtb) == 0 else gtb[idx])
-        picks = subsample_labels_batched(labels, self.batch_size_per_image, self.positive_fraction, 0, self.sample_generator)
+        self.last_counts = []
+        picks = subsample_labels_batched(labels, self.batch_size_per_image, self.positive_fraction, 0, self.sample_generator,
+                                         self.last_counts)
         for lab, (pos, neg) in zip(labels, picks):
             lab.fill_(-1)
             lab[pos] = 1
             lab[neg] = 0
         return labels, matched
+
+    def replay_sampling_draws(self, counts):
+        """Advance the sampling generator exactly as one ``label_and_sample_anchors`` call over images with these
+        (num_positive, num_negative) anchor counts would (used when a second, gradient-free RPN pass over the same
+        features is elided: its proposals are the first pass's, its random draws are still consumed)."""
+        for npos, nneg in counts:
+            torch.randperm(npos, generator=self.sample_generator)
+            torch.randperm(nneg, generator=self.sample_generator)
 
     def losses(self, anchors, logits, labels, deltas, matched):
         """rpn.py:365-429 (+ _dense_box_regression_loss box_regression.py:229-270, smooth-L1 beta 0 = L1)."""

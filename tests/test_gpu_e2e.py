@@ -45,8 +45,11 @@ def _oracle_cfg(cfg, kd):
                   rpn_post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, kd_regularization=kd)
 
 
-@pytest.mark.parametrize("kd", [False, True])
-def test_step_losses_and_grads_match_oracle(kd):
+@pytest.mark.parametrize("kd,share", [(False, True), (True, True), (True, False)])
+def test_step_losses_and_grads_match_oracle(kd, share):
+    """share=True: the region-level branch reuses the supervised pass's source-image res4 + RPN proposals (engine.py /
+    rcnn.py notes); share=False: every branch recomputes, as the reference does.  Both must match the oracle, which
+    always recomputes."""
     from cddmsl_amd import synthetic
     from cddmsl_amd.engine import SimpleTrainer
     from cddmsl_amd.solver import build_optimizer
@@ -58,6 +61,7 @@ def test_step_losses_and_grads_match_oracle(kd):
     opt = build_optimizer(cfg, model)
     tr = SimpleTrainer(model, iter([batch]), opt, cfg, clipcap_model=mapper, metrics_period=0)
     tr.iter = 20000   # past burn-in: all three branches live
+    tr.share_source_pass = share
     tr.buckets.zero()
     ld = tr.compute_losses(batch)
     sum(ld.values()).backward()
