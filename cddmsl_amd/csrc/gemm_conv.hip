@@ -25,6 +25,8 @@
 // K-tile = 8 chunks (128 B per row).  LDS rows are 128 B with chunk ^= (row>>1)&7 so that every
 // ds_read_b128 lane group hits 16 distinct 16-B slots (bank = (addr/4)%64).
 #include "common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -60,6 +62,9 @@ struct ConvArgs {
   FastDiv dWo, dHo, dcpp, dKW;
   int xrs, wrs;    // row strides in 16-byte chunks: A pixel -> pixel (default cpp), B row -> row (default Kc)
   long bx, bw, by; // byte strides of the batch axis (gridDim.y); 0 for plain convolutions
+#ifdef CDDMSL_STAMPS
+  unsigned long long* stamps;   // diagnostic build only (scratch/k256.hip): per-wave cycle sums of the phase segments
+#endif
 };
 
 template <typename T> struct Mma;
@@ -982,13 +987,361 @@ __global__ void k_weight_prep(const float* w, const float* scale, char* wf, char
 }
 
 static thread_local int g_batch = 1;   // set by the batched entry point around its launch
+static inline int g_batch_peek() { return g_batch; }
+
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4; 128x64 per wave), two wave groups ping-ponging on each SIMD.
+//
+// The 128x128 kernel above tops out near 1 PFLOP/s: both of its blocks on a CU stall at the same two barriers per
+// K-tile.  Here each SIMD hosts one wave of group 0 (wr = 0) and one of group 1 (wr = 1), group 1 running ONE barrier
+// behind: between two consecutive barriers one group issues LDS reads + LDS-DMA for its next quadrant while the other
+// runs that quadrant's MFMAs, so the matrix pipe always has a wave feeding it.  A K-tile (8 chunks) is four phases,
+// one 64x32 quadrant of the wave's 128x64 output each:
+//     phase 1  read B0            MFMA q00   stage A1 of the OTHER buffer with tile kt+1 (read in the previous phase 3)
+//     phase 2  read B1            MFMA q01   stage A0 of this buffer with tile kt+2   (read in the previous phase 4)
+//     phase 3  read A1            MFMA q11   stage B0 (read in phase 1), s_waitcnt vmcnt(4)
+//     phase 4  read A0 of kt+1    MFMA q10   stage B1 (read in phase 2)
+// Each half-tile (128 rows x 128 B: sub-tile i of both row groups / sub-tile j of all four column groups) is restaged
+// TWO phases after its last read: a phase's reads are retired (lgkmcnt(0), placed after the barrier so the LDS latency
+// overlaps the wait for the other group's MFMAs) before its MFMAs, i.e. before the barrier that opens the next phase,
+// which every wave passes before the phase after that issues its DMA -- for both groups despite the one-barrier stagger.
+// The phase-3 wait leaves the two youngest half-tiles (4 DMAs per thread) in flight and retires every older one: all
+// of tile kt+1, whose first read (A0, phase 4) comes after that phase's barrier.
+// LDS: [2 buffers][A|B][2 halves][128 rows x 8 chunks] = 128 KiB, swizzled like the 128x128 kernel.
+// Sources are buffer-addressed (buffer_load_dwordx4 ... offen lds): per-block base in SGPRs, a per-lane byte offset that
+// is constant over the K loop, and the running K / filter-tap position in the wave-uniform soffset -- the loop carries
+// no per-lane address arithmetic.  Filter-tap validity is a per-row bit mask (KH*KW <= 31 bits): an out-of-image tap or
+// an out-of-range row sets bit 31 of the lane's offset, which the range check turns into zeros written to LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, void* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, (int)soff, 0, 0);
+}
+
+template <typename T, bool TAPS>
+__global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2 * 2 * 2 * 128 * KCH];   // byte address = buf<<16 | ab<<15 | half<<14 | row*128 + slot*16
+  const int t = threadIdx.x, lane = t & 63;
+  p.x += (long)blockIdx.y * p.bx; p.w += (long)blockIdx.y * p.bw; p.y += (long)blockIdx.y * p.by;
+  const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wvu >> 2, wc = wvu & 3;
+  const int ntn = p.Cout >> 8;
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = lbid % ntn, tile_m = lbid / ntn;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int cl = (t & 7) ^ ((t >> 4) & 7);      // logical K chunk of this lane's LDS slot (slot ^ ((row>>1)&7))
+  const int nkt = p.Kc >> 3;
+  const int tpt = p.cpp >> 3;                   // K-tiles per filter tap
+
+  // ---- staging state.  Sources are addressed as buffer base (per block, SGPRs) + per-lane byte offset (constant over
+  // the K loop) + a wave-uniform running offset in the instruction's soffset: no per-lane pointer arithmetic in the loop.
+  // A lane whose row is outside M, or whose current filter tap falls outside the image, sets bit 31 of its offset:
+  // beyond num_records, the load then writes zeros into LDS.
+  //   A half h, piece i -> tile row i*128 + h*64 + (t>>3);   B half j, piece i -> tile col (2i + (t>>8))*64 + j*32 + ((t>>3)&31)
+  auto rowoff = [&](int m, int& iy0, int& ix0) {
+    const unsigned tq = fdiv((unsigned)m, p.dWo), ox = m - tq * p.Wo;
+    const unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
+    iy0 = (int)oy * p.stride - p.pad; ix0 = (int)ox * p.stride - p.pad;
+    return (((long)img * p.Hi + iy0) * p.Wi + ix0) * p.xrs * 16;
+  };
+  int iyb, ixb;
+  const long base_a = rowoff(m0, iyb, ixb);      // rows of one tile ascend from here (2*pad <= K-1, checked by the host)
+  const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + base_a), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * p.wrs * 16), 0, 0x7fffffff, 0x00020000);
+  unsigned va[2][2], vinv[2][2], vb[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + i * 128 + h * 64 + (t >> 3);
+      const bool vm = m < p.M;
+      int iy0, ix0;
+      const long ro = rowoff(vm ? m : m0, iy0, ix0);
+      va[h][i] = (unsigned)(ro - base_a) + cl * 16;
+      unsigned inv = 0;
+      if (TAPS) {
+        for (int ky = 0; ky < p.KH; ++ky)
+          for (int kx = 0; kx < p.KW; ++kx) {
+            const int iy = iy0 + ky, ix = ix0 + kx;
+            if (!(vm && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)) inv |= 1u << (ky * p.KW + kx);
+          }
+      } else if (!vm) va[h][i] |= 0x80000000u;
+      vinv[h][i] = inv;
+      vb[h][i] = (unsigned)(((2 * i + (t >> 8)) * 64 + h * 32 + ((t >> 3) & 31)) * p.wrs + cl) * 16;
+    }
+  const int step_col = (p.xrs - (p.cpp - KCH)) * 16;                               // next tap in the same filter row
+  const int step_row = ((p.Wi - (p.KW - 1)) * p.xrs - (p.cpp - KCH)) * 16;         // first tap of the next filter row
+  int left[2] = {tpt, tpt}, tap[2] = {0, 0}, kxs[2] = {0, 0};
+  unsigned soa[2] = {0, 0}, sob[2] = {0, 0};
+
+  char* const L = (char*)lds;
+  auto stageA = [&](auto H, int buf) {
+    constexpr int h = decltype(H)::value;
+    char* dst = L + (buf << 16) + (h << 14) + wvu * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned v = va[h][i];
+      if (TAPS) v |= __builtin_amdgcn_ubfe(vinv[h][i], (unsigned)tap[h], 1u) << 31;
+      blds16(ra_rsrc, v, soa[h], dst + i * 8192);
+    }
+    if (TAPS) {
+      int step = KCH * 16;
+      if (--left[h] == 0) {
+        left[h] = tpt; ++tap[h];
+        if (++kxs[h] == p.KW) { kxs[h] = 0; step = step_row; } else step = step_col;
+      }
+      soa[h] += step;
+    } else soa[h] += KCH * 16;
+  };
+  auto stageB = [&](auto J, int buf) {
+    constexpr int j = decltype(J)::value;
+    char* dst = L + (buf << 16) + (1 << 15) + (j << 14) + wvu * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) blds16(rb_rsrc, vb[j][i], sob[j], dst + i * 8192);
+    sob[j] += KCH * 16;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- fragment reads: per-lane byte addresses per k-step, buffer bit (1<<16) toggled by XOR; half / row-tile offsets are immediates
+  const int r32 = lane & 31, hh = lane >> 5, sw = (r32 >> 1) & 7;
+  unsigned ada[4], adb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    ada[ks] = (unsigned)(((wr * 64 + r32) * KCH + ((2 * ks + hh) ^ sw)) * 16);
+    adb[ks] = (unsigned)(((wc * 32 + r32) * KCH + ((2 * ks + hh) ^ sw)) * 16 + (1 << 15));
+  }
+  u32x4 fa0[2][4], fa1[2][4], fb0[4], fb1[4];
+  auto readA = [&](auto I, u32x4 (*fa)[4]) {
+    constexpr int i = decltype(I)::value;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const u32x4*)(L + ada[ks] + ((i << 14) + rt * 32 * KCH * 16));
+  };
+  auto readB = [&](auto J, u32x4* fb) {
+    constexpr int j = decltype(J)::value;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = *(const u32x4*)(L + adb[ks] + (j << 14));
+  };
+  auto flipA = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ada[ks] ^= 1u << 16;
+  };
+  auto flipB = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) adb[ks] ^= 1u << 16;
+  };
+#define CDDMSL_MMA_QUAD(I, J, FA, FB)                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
+    Mma<T>::step(acc[2 * (I)][J], FA[0][ks], FB[ks]);                               \
+    Mma<T>::step(acc[2 * (I) + 1][J], FA[1][ks], FB[ks]);                           \
+  }
+#ifdef CDDMSL_STAMPS   // segment sums: 0 load section, 1 first barrier + LDS wait, 2 MFMAs, 3 second barrier
+  unsigned long long st_sum[4] = {0, 0, 0, 0}, st_last = 0;
+#define CDDMSL_STAMP(K) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long tt_ = __builtin_readcyclecounter(); \
+                          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_sum[K] += tt_ - st_last; st_last = tt_; }
+#else
+#define CDDMSL_STAMP(K)
+#endif
+#define CDDMSL_PHASE_SYNC_IN()                                                      \
+  CDDMSL_STAMP(0)                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  __builtin_amdgcn_s_barrier();                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+  CDDMSL_STAMP(1)                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  __builtin_amdgcn_s_setprio(1);
+#define CDDMSL_PHASE_SYNC_OUT()                                                     \
+  __builtin_amdgcn_s_setprio(0);                                                    \
+  CDDMSL_STAMP(2)                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  __builtin_amdgcn_s_barrier();                                                     \
+  CDDMSL_STAMP(3)                                                                   \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- prologue: tile 0 complete, tile 1 without its A1 half (staged by phase 1 of tile 0); A0 of tile 0 is read ahead
+  stageA(I0{}, 0); stageA(I1{}, 0); stageB(I0{}, 0); stageB(I1{}, 0);
+  if (nkt > 1) {
+    stageA(I0{}, 1); stageB(I0{}, 1); stageB(I1{}, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  readA(I0{}, fa0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+#ifdef CDDMSL_STAMPS
+  st_last = __builtin_readcyclecounter();
+#endif
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int d = kt & 1;
+    const bool more1 = kt + 1 < nkt, more2 = kt + 2 < nkt;
+    // phase 1
+    readB(I0{}, fb0);
+    if (more1) stageA(I1{}, d ^ 1);
+    CDDMSL_PHASE_SYNC_IN();
+    CDDMSL_MMA_QUAD(0, 0, fa0, fb0);
+    CDDMSL_PHASE_SYNC_OUT();
+    // phase 2
+    readB(I1{}, fb1);
+    flipB();
+    if (more2) stageA(I0{}, d);
+    CDDMSL_PHASE_SYNC_IN();
+    CDDMSL_MMA_QUAD(0, 1, fa0, fb1);
+    CDDMSL_PHASE_SYNC_OUT();
+    // phase 3: the wait retires everything but the two youngest half-tiles, i.e. all of tile kt+1 (other buffer)
+    readA(I1{}, fa1);
+    flipA();
+    if (more2) {
+      stageB(I0{}, d);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CDDMSL_PHASE_SYNC_IN();
+    CDDMSL_MMA_QUAD(1, 1, fa1, fb1);
+    CDDMSL_PHASE_SYNC_OUT();
+    // phase 4
+    if (more1) readA(I0{}, fa0);
+    if (more2) stageB(I1{}, d);
+    CDDMSL_PHASE_SYNC_IN();
+    CDDMSL_MMA_QUAD(1, 0, fa1, fb0);
+    CDDMSL_PHASE_SYNC_OUT();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two groups (every wave has now passed all reads)
+#ifdef CDDMSL_STAMPS
+  if (p.stamps && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p.stamps[((long)blockIdx.x * 8 + wvu) * 4 + k] = st_sum[k];
+  }
+#endif
+#undef CDDMSL_MMA_QUAD
+#undef CDDMSL_PHASE_SYNC_IN
+#undef CDDMSL_PHASE_SYNC_OUT
+#undef CDDMSL_STAMP
+
+  // ---- epilogue: per-wave LDS transpose (32 rows x 64 cols f32 per pass, private 8 KiB region; DS ops of one wave
+  // execute in order, so no barrier is needed), 16-byte vector loads/stores of residual / mask / y.
+  float* ep = (float*)lds + wvu * 2048;
+  const int cg = lane & 7, rr = lane >> 3;
+  const int n = n0 + wc * 64 + cg * 8;
+  float sc[8], bi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = p.scale ? p.scale[n + j] : 1.f;
+    bi[j] = p.bias ? p.bias[n + j] : 0.f;
+  }
+  constexpr int ES = Mma<T>::ES;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int mb = m0 + wr * 128 + a * 32;
+    // operands of this pass first: their latency overlaps the transpose
+    u32x4 rres[4][ES / 2], rmsk[4][ES / 2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + rr + 8 * i;
+      const bool ok = m < p.M;
+#pragma unroll
+      for (int q = 0; q < ES / 2; ++q) {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        rres[i][q] = (ok && p.residual) ? ((const u32x4*)(p.residual + ((long)m * p.ldr + n) * ES))[q] : z;
+        rmsk[i][q] = (ok && p.relu_mask) ? ((const u32x4*)(p.relu_mask + ((long)m * p.ldm + n) * ES))[q] : z;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = (g & 3) + 8 * (g >> 2) + 4 * hh, col = b * 32 + r32;
+        ep[row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7))] = acc[a][b][g];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rr + 8 * i;
+      const int m = mb + row;
+      if (m >= p.M) continue;
+      const f32x4* src = (const f32x4*)(ep + row * 64 + ((cg ^ (row & 7)) << 3));
+      const f32x4 v0 = src[0], v1 = src[1];
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+      float rv[8], mv[8];
+      if (ES == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          rv[2 * j] = bf2f(rres[i][0][j] & 0xffff); rv[2 * j + 1] = bf2f(rres[i][0][j] >> 16);
+          mv[2 * j] = bf2f(rmsk[i][0][j] & 0xffff); mv[2 * j + 1] = bf2f(rmsk[i][0][j] >> 16);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          rv[j] = __builtin_bit_cast(f32x4, rres[i][0])[j]; rv[4 + j] = __builtin_bit_cast(f32x4, rres[i][ES / 2 - 1])[j];
+          mv[j] = __builtin_bit_cast(f32x4, rmsk[i][0])[j]; mv[4 + j] = __builtin_bit_cast(f32x4, rmsk[i][ES / 2 - 1])[j];
+        }
+      }
+      if (p.residual) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rv[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (p.relu_mask) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
+      }
+      if (p.out_f32 || ES == 4) {
+        f32x4* dst = (f32x4*)(p.y + ((long)m * p.ldy + n) * 4);
+        const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        dst[0] = o0; dst[1] = o1;
+      } else {
+        const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        *(u32x4*)(p.y + ((long)m * p.ldy + n) * 2) = o;
+      }
+    }
+  }
+}
+
+// Shapes the 256x256 kernel takes: whole 256-column tiles, K-tiles inside one filter tap, vector epilogue, <= 32 taps,
+// and enough tiles to fill the chip.  Environment CDDMSL_GEMM256 (read per launch, so one process can A/B): 0 = always the
+// 128x128 kernel, 2 = the 256x256 kernel wherever it is legal, unset/1 = the heuristic below.
+static bool use_gemm256(const ConvArgs& a) {
+  const char* e = getenv("CDDMSL_GEMM256");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0) return false;
+  const bool vec_ok = (a.ldy % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.relu_mask || a.ldm % 8 == 0);
+  if (a.pool || (a.cpp & 7) || (a.Cout & 255) || !vec_ok || a.KH * a.KW > 31) return false;
+  if (2 * a.pad > a.KH - 1 || 2 * a.pad > a.KW - 1) return false;   // rows of a tile must ascend in memory (per-block buffer base)
+  if (mode == 2) return true;                                   // forced (tests)
+  const long tiles = (long)((a.M + 255) / 256) * (a.Cout / 256) * g_batch_peek();
+  return tiles >= 224 && a.Kc >= 32;
+}
+
 
 template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   int ntn = (a.Cout + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
   long grid = (long)ntn * ntm;
   if (grid <= 0) return CDDMSL_OK;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
-  if (a.pool) hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
+  if (use_gemm256(a)) {
+    grid = (long)(a.Cout / 256) * ((a.M + 255) / 256);
+    if (a.KH == 1 && a.KW == 1 && a.pad == 0)
+      hipLaunchKernelGGL((k_conv_fwd256<T, false>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_conv_fwd256<T, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
+  } else if (a.pool) hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid, (unsigned)g_batch), dim3(256), 0, st, a);
   return launch_status();
 }

@@ -141,3 +141,49 @@ def test_batched_gemms(dtype, tol):
     hip.gemm_tn_batched(Ar.cuda(), Xr.cuda(), out, Mr, 64, 128, Hh * 64, Hh * 128, 128, Hh, 64, 128, 64 * 128, accumulate=True)
     ref = 1.0 + torch.cat([Ar.float()[:, h * 64:(h + 1) * 64].t() @ Xr.float()[:, h * 128:(h + 1) * 128] for h in range(Hh)], dim=0)
     assert (out.cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+
+
+CASES256 = [
+    # N, H, W, Cin, Cout, K, pad      (Cout % 256 == 0, Cin a whole number of K-tiles)
+    (2, 19, 23, 64, 256, 3, 1),       # ragged M (874 rows), 9 taps, one K-tile per tap (bf16)
+    (1, 30, 33, 128, 512, 1, 0),      # two column tiles, 2 K-tiles
+    (3, 14, 14, 192, 256, 3, 1),      # odd number of K-tiles (27)
+    (1, 20, 20, 64, 256, 1, 0),       # a single K-tile (bf16): prologue-only pipeline
+    (4, 28, 28, 256, 768, 3, 1),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("case", CASES256)
+def test_conv_fwd_256_tile_kernel(case, dtype, tol, monkeypatch):
+    """The 256x256 ping-pong kernel (forced with CDDMSL_GEMM256=2) against ATen fp32 and against the 128x128 kernel:
+    FrozenBN scale/bias + residual + ReLU forward, and the masked dgrad form."""
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout, K, p = case
+    x = _rand((N, Cin, H, W), 21).to(dtype).float()
+    w = (_rand((Cout, Cin, K, K), 22) * (Cin * K * K) ** -0.5).to(dtype).float()
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(23)) + 0.5
+    bias = _rand((Cout,), 24, 0.1)
+    conv = F.conv2d(x, w, padding=p)
+    res = _rand(tuple(conv.shape), 25).to(dtype).float()
+    y_ref = F.relu(conv * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res)
+    dev = "cuda"
+    xg = _nhwc(x).to(dev, dtype)
+    wf, wd = hip.weight_prep(w.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), dtype)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CDDMSL_GEMM256", mode)
+        y = hip.conv_fwd(xg, wf, scale.to(dev), bias.to(dev), _nhwc(res).to(dev, dtype), relu=True, stride=1, pad=p)
+        # dgrad form: input = a [.., Cout] gradient, weights = wd (Cin outputs ... only legal for the 256 kernel if Cin % 256 == 0)
+        msk = hip.conv_fwd(xg, wf, relu_mask=_nhwc(res).to(dev, dtype), stride=1, pad=p)
+        torch.cuda.synchronize()
+        out[mode] = (y.float().cpu(), msk.float().cpu())
+    y_cpu = out["2"][0].permute(0, 3, 1, 2)
+    err = (y_cpu - y_ref).abs().max() / y_ref.abs().max()
+    assert err < tol, f"fwd err {err}"
+    m_ref = conv * (res > 0)
+    errm = (out["2"][1].permute(0, 3, 1, 2) - m_ref).abs().max() / m_ref.abs().max()
+    assert errm < tol, f"masked err {errm}"
+    # the two kernels accumulate K in the same order (chunk by chunk, fp32): results agree to rounding of the store dtype
+    for a, b in zip(out["0"], out["2"]):
+        assert (a - b).abs().max() <= tol * a.abs().max()
