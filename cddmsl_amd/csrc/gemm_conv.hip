@@ -966,6 +966,238 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_dma(WgradArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// wgrad / TN GEMM on the 256x256 ping-pong structure of k_conv_fwd256 (bf16): output tile 256 n x 256 k, reduction
+// tiles of 64 m rows, 8 waves (2 over n x 4 over k; 128 n x 64 k per wave), the two wave groups one barrier apart.
+// Operands stay row-major in LDS ([64 rows][256 B] images, chunk ^= fsw(row)) and are read transposed
+// (ds_read_b64_tr_b16).  A half-tile = one 16 KiB image: dY half h = the 64 columns {wn*128 + h*64 ..} of both wave
+// rows, X half j = the 32 columns {wk*64 + j*32 ..} of all four wave columns.  Phases, restaging distance and the
+// counted vmcnt are those of k_conv_fwd256.  Sources are buffer-addressed: per-lane offset constant, the m walk in soffset;
+// rows past M and out-of-image filter taps set bit 31 of the lane offset (-> zeros).  Tap validity is recomputed per
+// reduction tile for the lane's two rows (2 fdiv each) in the phase that stages the first X half.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2 * 2 * 2 * 64 * 16];   // byte = buf<<16 | ab<<15 | half<<14 | row*256 + slot*16
+  const int t = threadIdx.x, lane = t & 63;
+  p.x += (long)blockIdx.y * p.bx; p.dy += (long)blockIdx.y * p.bd;
+  char* outp = (char*)p.dw + (long)blockIdx.y * p.bo;
+  const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wvu >> 2, wk = wvu & 3;
+  const int ntn = p.Cout >> 8, ntk = p.K >> 8;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_k = bid % ntk; bid /= ntk;
+  const int tile_n = bid % ntn; bid /= ntn;
+  const int n0 = tile_n * 256, k0 = tile_k * 256;
+  const int mt0 = bid * p.mtiles_per_split;
+  const int nmt = min(p.mtiles_per_split, (p.M + WM - 1) / WM - mt0);
+  const bool taps = !(p.KH == 1 && p.KW == 1);
+
+  // ---- staging: thread -> LDS slot (row i*32 + (t>>4), slot t&15), logical chunk cl of that slot
+  const int rb = t >> 4, cl = (t & 15) ^ fsw(rb);
+  const int gd = (cl >> 3) * 16 + (cl & 7);                 // dY chunk within the 256-column tile (+ 8 per half: immediate)
+  const int gx = (cl >> 2) * 8 + (cl & 3);                  // X chunk within the 256-column tile (+ 4 per half: immediate)
+  const int kc = (k0 >> 3) + gx;
+  const int pp = kc / p.cpp, coff = kc - pp * p.cpp;
+  const int ky = pp / p.KW, kx = pp - ky * p.KW;
+  unsigned vd[2], vx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    vd[i] = (unsigned)((i * 32 + rb) * p.ldd * 2 + gd * 16);
+    vx[i] = (unsigned)((((i * 32 + rb) + ky * p.Wi + kx) * p.xrs + coff) * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + ((long)mt0 * WM * p.ldd + n0) * 2), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + ((long)mt0 * WM - p.pad * p.Wi - p.pad) * p.xrs * 16), 0, 0x80000000u, 0x00020000);
+  const unsigned dstep = (unsigned)(WM * p.ldd * 2), xstep = (unsigned)(WM * p.xrs * 16);
+  const int mrow = mt0 * WM + rb;                            // + T*64 + i*32
+
+  char* const L = (char*)lds;
+  auto stageD = [&](auto H, int buf, int T) {                // dY half h of reduction tile T (relative to mt0)
+    constexpr int h = decltype(H)::value;
+    char* dst = L + (buf << 16) + (h << 14) + wvu * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned inv = (mrow + T * WM + i * 32 < p.M) ? 0u : 0x80000000u;
+      // the instruction's immediate offset moves BOTH the global and the LDS address: take it back out of the LDS base (M0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(dst + i * 8192 - h * 128), 16,
+                                               (int)(vd[i] | inv), (int)(T * dstep), h * 128, 0);
+    }
+  };
+  unsigned xinv[2];
+  auto validX = [&](int T) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mrow + T * WM + i * 32;
+      bool ok = m < p.M;
+      if (taps) {
+        const unsigned mm = min((unsigned)m, (unsigned)(p.M - 1));
+        const unsigned tq = fdiv(mm, p.dWo);
+        const unsigned ox = mm - tq * p.Wo;
+        const unsigned oy = tq - fdiv(tq, p.dHo) * p.Ho;
+        ok = ok & ((unsigned)((int)oy - p.pad + ky) < (unsigned)p.Hi) & ((unsigned)((int)ox - p.pad + kx) < (unsigned)p.Wi);
+      }
+      xinv[i] = ok ? 0u : 0x80000000u;
+    }
+  };
+  auto stageX = [&](auto J, int buf, int T) {
+    constexpr int j = decltype(J)::value;
+    char* dst = L + (buf << 16) + (1 << 15) + (j << 14) + wvu * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + i * 8192 - j * 64), 16,
+                                               (int)(vx[i] | xinv[i]), (int)(T * xstep), j * 64, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- transposed fragment reads: per-lane byte addresses (absolute LDS), buffer bit toggled by XOR, half / 16-row step as immediates
+  const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)L;
+  unsigned adA[2][2], adB[2];
+  {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const TrFragS<__bf16>::Off o = TrFragS<__bf16>::prep(wn * 64 + a * 32, lane);
+      adA[a][0] = lbase + o.o0; adA[a][1] = lbase + o.o1;
+    }
+    const TrFragS<__bf16>::Off o = TrFragS<__bf16>::prep(wk * 32, lane);
+    adB[0] = lbase + (1u << 15) + o.o0; adB[1] = lbase + (1u << 15) + o.o1;
+  }
+  u32x4 fa0[2][4], fa1[2][4], fb0[4], fb1[4];
+#define CDDMSL_TR2(DST, A0, A1, IMM)                                                             \
+  { u32x2 q0_, q1_;                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q0_) : "v"(A0), "i"(IMM));         \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q1_) : "v"(A1), "i"(IMM));         \
+    DST = u32x4{q0_[0], q0_[1], q1_[0], q1_[1]}; }
+#define CDDMSL_READ_A(HALF, FA)                                                                  \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                \
+    CDDMSL_TR2(FA[a][0], adA[a][0], adA[a][1], ((HALF) << 14) + 0 * 4096)                        \
+    CDDMSL_TR2(FA[a][1], adA[a][0], adA[a][1], ((HALF) << 14) + 1 * 4096)                        \
+    CDDMSL_TR2(FA[a][2], adA[a][0], adA[a][1], ((HALF) << 14) + 2 * 4096)                        \
+    CDDMSL_TR2(FA[a][3], adA[a][0], adA[a][1], ((HALF) << 14) + 3 * 4096) }
+#define CDDMSL_READ_B(HALF, FB)                                                                  \
+  CDDMSL_TR2(FB[0], adB[0], adB[1], ((HALF) << 14) + 0 * 4096)                                   \
+  CDDMSL_TR2(FB[1], adB[0], adB[1], ((HALF) << 14) + 1 * 4096)                                   \
+  CDDMSL_TR2(FB[2], adB[0], adB[1], ((HALF) << 14) + 2 * 4096)                                   \
+  CDDMSL_TR2(FB[3], adB[0], adB[1], ((HALF) << 14) + 3 * 4096)
+#define CDDMSL_FLIP_A() { adA[0][0] ^= 1u << 16; adA[0][1] ^= 1u << 16; adA[1][0] ^= 1u << 16; adA[1][1] ^= 1u << 16; }
+#define CDDMSL_FLIP_B() { adB[0] ^= 1u << 16; adB[1] ^= 1u << 16; }
+#define CDDMSL_MMA_QUAD(I, J, FA, FB)                                               \
+  _Pragma("unroll") for (int ms = 0; ms < 4; ++ms) {                                \
+    Mma<__bf16>::step(acc[2 * (I)][J], FA[0][ms], FB[ms]);                          \
+    Mma<__bf16>::step(acc[2 * (I) + 1][J], FA[1][ms], FB[ms]);                      \
+  }
+// The transposed reads are inline asm (see TrFragS): the wait that retires them names the fragments as read-write
+// operands, so no MFMA that consumes them can be placed above it; the empty statement after a quadrant's MFMAs names its
+// accumulators, so those MFMAs cannot sink below the phase's closing barrier (register-only instructions are otherwise
+// free to cross barriers and sched_barrier alike).
+#define CDDMSL_WAIT4(F) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]) :: "memory");
+#define CDDMSL_WAIT8(F) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0][0]), "+v"(F[0][1]), "+v"(F[0][2]), "+v"(F[0][3]), \
+                                     "+v"(F[1][0]), "+v"(F[1][1]), "+v"(F[1][2]), "+v"(F[1][3]) :: "memory");
+#define CDDMSL_PHASE_SYNC_IN(WAIT)                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  __builtin_amdgcn_s_barrier();                                                     \
+  WAIT                                                                              \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  __builtin_amdgcn_s_setprio(1);
+#define CDDMSL_PHASE_SYNC_OUT(I, J)                                                 \
+  asm volatile("" : "+v"(acc[2 * (I)][J]), "+v"(acc[2 * (I) + 1][J]));              \
+  __builtin_amdgcn_s_setprio(0);                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                \
+  __builtin_amdgcn_s_barrier();                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+
+  if (nmt > 0) {
+    // prologue: tile 0 complete, tile 1 without its dY half 1 (staged by phase 1 of tile 0); dY half 0 of tile 0 is read ahead
+    validX(0);
+    stageD(I0{}, 0, 0); stageD(I1{}, 0, 0); stageX(I0{}, 0, 0); stageX(I1{}, 0, 0);
+    if (nmt > 1) {
+      validX(1);
+      stageD(I0{}, 1, 1); stageX(I0{}, 1, 1); stageX(I1{}, 1, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    CDDMSL_READ_A(0, fa0)
+    CDDMSL_WAIT8(fa0)
+    if (wn == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int kt = 0; kt < nmt; ++kt) {
+      const int d = kt & 1;
+      const bool more1 = kt + 1 < nmt, more2 = kt + 2 < nmt;
+      // phase 1
+      CDDMSL_READ_B(0, fb0)
+      if (more1) stageD(I1{}, d ^ 1, kt + 1);
+      CDDMSL_PHASE_SYNC_IN(CDDMSL_WAIT4(fb0))
+      CDDMSL_MMA_QUAD(0, 0, fa0, fb0);
+      CDDMSL_PHASE_SYNC_OUT(0, 0)
+      // phase 2
+      CDDMSL_READ_B(1, fb1)
+      CDDMSL_FLIP_B()
+      if (more2) stageD(I0{}, d, kt + 2);
+      CDDMSL_PHASE_SYNC_IN(CDDMSL_WAIT4(fb1))
+      CDDMSL_MMA_QUAD(0, 1, fa0, fb1);
+      CDDMSL_PHASE_SYNC_OUT(0, 1)
+      // phase 3
+      CDDMSL_READ_A(1, fa1)
+      CDDMSL_FLIP_A()
+      if (more2) {
+        validX(kt + 2);
+        stageX(I0{}, d, kt + 2);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      CDDMSL_PHASE_SYNC_IN(CDDMSL_WAIT8(fa1))
+      CDDMSL_MMA_QUAD(1, 1, fa1, fb1);
+      CDDMSL_PHASE_SYNC_OUT(1, 1)
+      // phase 4
+      if (more1) { CDDMSL_READ_A(0, fa0) }
+      if (more2) stageX(I1{}, d, kt + 2);
+      CDDMSL_PHASE_SYNC_IN(CDDMSL_WAIT8(fa0))
+      CDDMSL_MMA_QUAD(1, 0, fa1, fb0);
+      CDDMSL_PHASE_SYNC_OUT(1, 0)
+    }
+    if (wn == 0) __builtin_amdgcn_s_barrier();
+  }
+#undef CDDMSL_TR2
+#undef CDDMSL_WAIT4
+#undef CDDMSL_WAIT8
+#undef CDDMSL_READ_A
+#undef CDDMSL_READ_B
+#undef CDDMSL_FLIP_A
+#undef CDDMSL_FLIP_B
+#undef CDDMSL_MMA_QUAD
+#undef CDDMSL_PHASE_SYNC_IN
+#undef CDDMSL_PHASE_SYNC_OUT
+
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int k = k0 + wk * 64 + b * 32 + r;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int n = n0 + wn * 128 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        const float v = acc[a][b][g] * (p.scale ? p.scale[n] : 1.f);
+        const long o = (long)n * p.ldo + k;
+        if (p.direct == 0) atomicAdd((float*)outp + o, v);
+        else if (p.direct == 1) ((float*)outp)[o] = v;
+        else Mma<__bf16>::store(outp + o * 2, v);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight_prep: f32 master [Cout][KH][KW][Cin] -> T forward weights (same layout) and T dgrad weights
 // Wd[cin][KH-1-ky][KW-1-kx][cout] = W[cout][ky][kx][cin] * scale[cout]
 // ------------------------------------------------------------------------------------------------
@@ -1159,7 +1391,8 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   CDDMSL_STAMP(1)                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                \
   __builtin_amdgcn_s_setprio(1);
-#define CDDMSL_PHASE_SYNC_OUT()                                                     \
+#define CDDMSL_PHASE_SYNC_OUT(I, J)                                                 \
+  asm volatile("" : "+v"(acc[2 * (I)][J]), "+v"(acc[2 * (I) + 1][J]));   /* the MFMAs above cannot sink below the barrier */ \
   __builtin_amdgcn_s_setprio(0);                                                    \
   CDDMSL_STAMP(2)                                                                   \
   __builtin_amdgcn_sched_barrier(0);                                                \
@@ -1191,14 +1424,14 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     if (more1) stageA(I1{}, d ^ 1);
     CDDMSL_PHASE_SYNC_IN();
     CDDMSL_MMA_QUAD(0, 0, fa0, fb0);
-    CDDMSL_PHASE_SYNC_OUT();
+    CDDMSL_PHASE_SYNC_OUT(0, 0);
     // phase 2
     readB(I1{}, fb1);
     flipB();
     if (more2) stageA(I0{}, d);
     CDDMSL_PHASE_SYNC_IN();
     CDDMSL_MMA_QUAD(0, 1, fa0, fb1);
-    CDDMSL_PHASE_SYNC_OUT();
+    CDDMSL_PHASE_SYNC_OUT(0, 1);
     // phase 3: the wait retires everything but the two youngest half-tiles, i.e. all of tile kt+1 (other buffer)
     readA(I1{}, fa1);
     flipA();
@@ -1210,13 +1443,13 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     }
     CDDMSL_PHASE_SYNC_IN();
     CDDMSL_MMA_QUAD(1, 1, fa1, fb1);
-    CDDMSL_PHASE_SYNC_OUT();
+    CDDMSL_PHASE_SYNC_OUT(1, 1);
     // phase 4
     if (more1) readA(I0{}, fa0);
     if (more2) stageB(I1{}, d);
     CDDMSL_PHASE_SYNC_IN();
     CDDMSL_MMA_QUAD(1, 0, fa1, fb0);
-    CDDMSL_PHASE_SYNC_OUT();
+    CDDMSL_PHASE_SYNC_OUT(1, 0);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two groups (every wave has now passed all reads)
 #ifdef CDDMSL_STAMPS
@@ -1375,6 +1608,23 @@ extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const floa
   return dtype == 0 ? conv_fwd_launch<__bf16>(a, (hipStream_t)stream) : conv_fwd_launch<float>(a, (hipStream_t)stream);
 }
 
+// The 256x256 wgrad kernel takes bf16 "same" problems with whole 256-wide output tiles and 8-chunk-aligned pixels
+// (so the two X halves of a lane share one filter tap).  CDDMSL_GEMM256 as for the forward kernel (0 = never, 2 = always).
+static bool wgrad256_ok(const WgradArgs& a, int batch) {
+  const char* e = getenv("CDDMSL_GEMM256");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0) return false;
+  if ((a.Cout & 255) || (a.K & 255) || (a.cpp & 7) || (a.ldd & 7)) return false;
+  if (mode == 2) return true;
+  // long reductions only: each block ends with 64 Ki scalar atomics, which a short m range cannot amortise
+  return (long)(a.Cout / 256) * (a.K / 256) * batch * ((a.M + WM - 1) / WM) >= 32768;
+}
+// buffer addressing: lane offset + soffset must stay below 2 GiB inside one block's reduction range
+static bool wgrad256_span_ok(const WgradArgs& a) {
+  const long rowb = (long)(a.ldd * 2 > a.xrs * 16 ? a.ldd * 2 : a.xrs * 16);
+  return ((long)a.mtiles_per_split * WM + WM + 2L * a.Wi + 2) * rowb + (1L << 20) < (1L << 31);
+}
+
 extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const float* scale, int Nimg, int Hi,
                                  int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int pool, int ldd,
                                  int dtype, void* stream) {
@@ -1409,6 +1659,22 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   long grid = tiles * splits;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   const bool same = !pool && stride == 1 && a.Ho == Hi && a.Wo == Wi;   // LDS-DMA kernel: output pixel == input pixel
+  if (same && dtype == 0 && wgrad256_ok(a, 1)) {
+    // 256x256 ping-pong kernel: one block per CU, so fewer and longer splits
+    long tiles2 = (long)(Cout / 256) * (a.K / 256);
+    long want2 = (640 + tiles2 - 1) / tiles2;
+    long maxs2 = (total_mt + 15) / 16;
+    long sp = want2 < 1 ? 1 : (want2 > maxs2 ? maxs2 : want2);
+    if (sp < 1) sp = 1;
+    int keep = a.mtiles_per_split;
+    a.mtiles_per_split = (int)((total_mt + sp - 1) / sp);
+    sp = (total_mt + a.mtiles_per_split - 1) / a.mtiles_per_split;
+    if (wgrad256_span_ok(a)) {
+      hipLaunchKernelGGL(k_wgrad256, dim3((unsigned)(tiles2 * sp)), dim3(512), 0, (hipStream_t)stream, a);
+      return launch_status();
+    }
+    a.mtiles_per_split = keep;
+  }
   if (same) {
     if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);

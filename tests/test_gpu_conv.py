@@ -187,3 +187,40 @@ def test_conv_fwd_256_tile_kernel(case, dtype, tol, monkeypatch):
     # the two kernels accumulate K in the same order (chunk by chunk, fp32): results agree to rounding of the store dtype
     for a, b in zip(out["0"], out["2"]):
         assert (a - b).abs().max() <= tol * a.abs().max()
+
+
+CASES_W256 = [
+    # N, H, W, Cin, Cout, K, pad     (Cout % 256 == 0, KH*KW*Cin % 256 == 0, Cin % 64 == 0)
+    (3, 14, 14, 256, 256, 3, 1),     # M = 588: ragged last reduction tile, 9 taps
+    (2, 9, 11, 256, 512, 1, 0),      # 1x1: two n tiles
+    (5, 7, 7, 512, 256, 3, 1),       # RoI-head geometry (7x7 images), 18 k tiles
+    (1, 5, 5, 256, 256, 3, 1),       # M = 25: a single partial reduction tile
+    (9, 14, 14, 512, 512, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES_W256)
+def test_conv_wgrad_256_tile_kernel(case, monkeypatch):
+    """bf16 wgrad on the 256x256 ping-pong kernel (forced) vs ATen fp32 and vs the 128x128 LDS-DMA kernel."""
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout, K, p = case
+    dtype, tol = torch.bfloat16, 2e-2
+    x = _rand((N, Cin, H, W), 31).to(dtype).float().requires_grad_(False)
+    dy = _rand((N, Cout, H, W), 32).to(dtype).float()
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(33)) + 0.5
+    w = torch.zeros(Cout, Cin, K, K, requires_grad=True)
+    (F.conv2d(x, w, padding=p) * scale.view(1, -1, 1, 1)).backward(dy)
+    dev = "cuda"
+    xg, dyg = _nhwc(x).to(dev, dtype), _nhwc(dy).to(dev, dtype)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CDDMSL_GEMM256", mode)
+        dw = hip.conv_wgrad(xg, dyg, (Cout, K, K, Cin), scale.to(dev), stride=1, pad=p)
+        torch.cuda.synchronize()
+        out[mode] = dw.cpu().permute(0, 3, 1, 2)
+    ref = w.grad
+    for mode in ("0", "2"):
+        err = (out[mode] - ref).abs().max() / ref.abs().max()
+        assert err < tol, (mode, float(err))
+    # same products, fp32 accumulation in a different split order
+    assert (out["0"] - out["2"]).abs().max() <= 1e-4 * ref.abs().max()
