@@ -1475,11 +1475,13 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     bi[j] = p.bias ? p.bias[n + j] : 0.f;
   }
   constexpr int ES = Mma<T>::ES;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
+  // bf16: residual / mask rows are fetched TWO passes ahead (two register sets, static indices): with one block per CU
+  // nothing else hides their HBM latency; passes 0 and 1 are requested together before any transpose starts.  The f32
+  // parity instantiation (twice the registers per row) fetches one pass ahead of its use only.
+  constexpr int DEPTH = ES == 2 ? 2 : 1;
+  u32x4 rresb[DEPTH][4][ES / 2], rmskb[DEPTH][4][ES / 2];
+  auto fetch = [&](int a, u32x4 (*rres)[ES / 2], u32x4 (*rmsk)[ES / 2]) {
     const int mb = m0 + wr * 128 + a * 32;
-    // operands of this pass first: their latency overlaps the transpose
-    u32x4 rres[4][ES / 2], rmsk[4][ES / 2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mb + rr + 8 * i;
@@ -1491,6 +1493,14 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
         rmsk[i][q] = (ok && p.relu_mask) ? ((const u32x4*)(p.relu_mask + ((long)m * p.ldm + n) * ES))[q] : z;
       }
     }
+  };
+  if (DEPTH == 2) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int mb = m0 + wr * 128 + a * 32;
+    if (DEPTH == 1) fetch(a, rresb[0], rmskb[0]);
+    u32x4 (*rres)[ES / 2] = rresb[a % DEPTH];
+    u32x4 (*rmsk)[ES / 2] = rmskb[a % DEPTH];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -1544,6 +1554,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
         *(u32x4*)(p.y + ((long)m * p.ldy + n) * 2) = o;
       }
     }
+    if (DEPTH == 2 && a + 2 < 4) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
   }
 }
 
