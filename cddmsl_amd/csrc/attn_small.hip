@@ -1,0 +1,223 @@
+// Fused multi-head attention for SHORT sequences (the ClipCap TransformerMapper: 80 tokens, 8 heads of 96 --
+// detectron2/modeling/backbone/clipcap/clipcap.py:39-83, MultiHeadAttention.forward: softmax(QK^T * scale) V with no mask).
+// bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 softmax.  One workgroup = one (sequence, head); three waves, wave w owns
+// query rows [32w, 32w+32) (tokens padded to 96 with zero rows, head dim = 96 = 3 MFMA tiles).
+//
+// Q, K, V (and dO, P, dS in the backward) live as row-major [96][96] bf16 images in LDS (row stride 208 B).  Every
+// product reads its operands straight from those images: an operand whose contraction index runs along the image
+// COLUMNS is read with ds_read_b128, one whose contraction index runs along the image ROWS with ds_read_b64_tr_b16
+// (transposing read) -- so no transposed copy of anything is ever made:
+//     S  = Q K^T      (cols, cols)        O  = P V        (cols, rows)
+//     dP = dO V^T     (cols, cols)        dV = P^T dO     (rows, rows)
+//     dQ = dS K       (cols, rows)        dK = dS^T Q     (rows, rows)
+// The backward recomputes S and P from Q, K (cheaper than saving them), dS = P o (dP - rowsum(dP o P)) * scale.
+#include "common.h"
+
+namespace {
+
+constexpr int AT = 96;        // padded tokens = head dim
+constexpr int ARS = 208;      // image row stride in bytes (192 data + 16 pad: b128 reads of 16 rows hit 16 distinct slots)
+constexpr int IMG = AT * ARS; // 19968 B
+
+struct AttnArgs {
+  const char *q, *k, *v, *dout;
+  char *o, *dq, *dk, *dv;
+  int nseq, t, heads, ldq, ldk, ldv, ldo;   // row strides in elements
+  float scale;
+};
+
+// fragment of an operand whose contraction index runs along the image columns: lane (r, hh) <- row row0 + r, elements 16 kk + 8 hh ..+8
+__device__ __forceinline__ u32x4 frag_cols(const char* img, int row0, int kk, int lane) {
+  return *(const u32x4*)(img + (row0 + (lane & 31)) * ARS + (kk * 16 + (lane >> 5) * 8) * 2);
+}
+// fragment of an operand whose contraction index runs along the image rows: lane (c, hh) <- column col0 + c, rows 16 kk + 8 hh ..+8
+__device__ __forceinline__ u32x4 frag_rows(const char* img, int col0, int kk, int lane) {
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3, hh = g >> 1;
+  const int col = col0 + 16 * (g & 1) + 4 * pp;
+  const char* a0 = img + (kk * 16 + 8 * hh + q) * ARS + col * 2;
+  const i16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)a0);
+  const i16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(a0 + 4 * ARS));
+  const u32x2 p0 = __builtin_bit_cast(u32x2, v0), p1 = __builtin_bit_cast(u32x2, v1);
+  return u32x4{p0[0], p0[1], p1[0], p1[1]};
+}
+__device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ float half_sum(float v) {   // over the 32 lanes that share lane>>5
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// global [t rows][96 cols] (row stride ld elements) -> LDS image, rows t..95 zeroed
+__device__ __forceinline__ void stage(char* img, const char* g, int t, int ld, int tid) {
+  for (int c = tid; c < AT * 12; c += 192) {
+    const int row = c / 12, ch = c - row * 12;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < t) v = *(const u32x4*)(g + ((long)row * ld) * 2 + ch * 16);
+    *(u32x4*)(img + row * ARS + ch * 16) = v;
+  }
+}
+// C tile (32 x 32, rows row0.., cols col0..) -> bf16 image
+__device__ __forceinline__ void put_tile(char* img, int row0, int col0, const f32x16& a, int lane) {
+  const int c = col0 + (lane & 31), hh = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int r = row0 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+    *(unsigned short*)(img + r * ARS + c * 2) = f2bf(a[g]);
+  }
+}
+// C tile -> global bf16 rows < t
+__device__ __forceinline__ void store_tile(char* gp, int ld, int t, int row0, int col0, const f32x16& a, int lane) {
+  const int c = col0 + (lane & 31), hh = lane >> 5;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int r = row0 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+    if (r < t) *(unsigned short*)(gp + ((long)r * ld + c) * 2) = f2bf(a[g]);
+  }
+}
+
+// S = scale * Q K^T for this wave's 32 query rows, masked softmax over the t valid columns -> P (f32, C layout)
+__device__ __forceinline__ void scores_softmax(const char* Qi, const char* Ki, int i0, int t, float scale, int lane, f32x16 (&P)[3]) {
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P[jt][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) mma(P[jt], frag_cols(Qi, i0, kk, lane), frag_cols(Ki, jt * 32, kk, lane));
+  }
+  const int c = lane & 31;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    float s[3], m = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) {
+      s[jt] = (jt * 32 + c < t) ? P[jt][g] * scale : -INFINITY;
+      m = fmaxf(m, s[jt]);
+    }
+    m = half_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) { s[jt] = __expf(s[jt] - m); sum += s[jt]; }
+    sum = half_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) P[jt][g] = s[jt] * inv;
+  }
+}
+
+__global__ __launch_bounds__(192) void k_attn_small_fwd(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
+  char *Qi = lds, *Ki = lds + IMG, *Vi = lds + 2 * IMG, *Pi = lds + 3 * IMG;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int s = blockIdx.x / p.heads, h = blockIdx.x - s * p.heads;
+  const long row0 = (long)s * p.t;
+  stage(Qi, p.q + (row0 * p.ldq + h * AT) * 2, p.t, p.ldq, tid);
+  stage(Ki, p.k + (row0 * p.ldk + h * AT) * 2, p.t, p.ldk, tid);
+  stage(Vi, p.v + (row0 * p.ldv + h * AT) * 2, p.t, p.ldv, tid);
+  __syncthreads();
+  const int i0 = 32 * w;
+  f32x16 P[3];
+  scores_softmax(Qi, Ki, i0, p.t, p.scale, lane, P);
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) put_tile(Pi, i0, jt * 32, P[jt], lane);   // rows of this wave only: in-order DS, no barrier
+  char* op = p.o + (row0 * p.ldo + h * AT) * 2;
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) mma(acc, frag_cols(Pi, i0, kk, lane), frag_rows(Vi, ct * 32, kk, lane));
+    store_tile(op, p.ldo, p.t, i0, ct * 32, acc, lane);
+  }
+}
+
+__global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[6 * IMG];
+  char *Qi = lds, *Ki = lds + IMG, *Vi = lds + 2 * IMG, *Di = lds + 3 * IMG, *Pi = lds + 4 * IMG, *Si = lds + 5 * IMG;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int s = blockIdx.x / p.heads, h = blockIdx.x - s * p.heads;
+  const long row0 = (long)s * p.t;
+  stage(Qi, p.q + (row0 * p.ldq + h * AT) * 2, p.t, p.ldq, tid);
+  stage(Ki, p.k + (row0 * p.ldk + h * AT) * 2, p.t, p.ldk, tid);
+  stage(Vi, p.v + (row0 * p.ldv + h * AT) * 2, p.t, p.ldv, tid);
+  stage(Di, p.dout + (row0 * p.ldo + h * AT) * 2, p.t, p.ldo, tid);
+  __syncthreads();
+  const int i0 = 32 * w;
+  f32x16 P[3], dP[3];
+  scores_softmax(Qi, Ki, i0, p.t, p.scale, lane, P);
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dP[jt][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) mma(dP[jt], frag_cols(Di, i0, kk, lane), frag_cols(Vi, jt * 32, kk, lane));
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    float rs = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) rs += dP[jt][g] * P[jt][g];
+    rs = half_sum(rs);
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) dP[jt][g] = P[jt][g] * (dP[jt][g] - rs) * p.scale;    // dS (masked columns: P = 0)
+  }
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) { put_tile(Pi, i0, jt * 32, P[jt], lane); put_tile(Si, i0, jt * 32, dP[jt], lane); }
+  __syncthreads();                                  // dV, dK need every wave's rows of P and dS
+  char* dqp = p.dq + (row0 * p.ldq + h * AT) * 2;
+  char* dkp = p.dk + (row0 * p.ldk + h * AT) * 2;
+  char* dvp = p.dv + (row0 * p.ldv + h * AT) * 2;
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    f32x16 aq, ak, av;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ak[r] = 0.f; av[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+      mma(aq, frag_cols(Si, i0, kk, lane), frag_rows(Ki, ct * 32, kk, lane));     // dQ[i] = sum_j dS[i][j] K[j]
+      mma(av, frag_rows(Pi, i0, kk, lane), frag_rows(Di, ct * 32, kk, lane));     // dV[j] = sum_i P[i][j] dO[i]   (j0 = i0)
+      mma(ak, frag_rows(Si, i0, kk, lane), frag_rows(Qi, ct * 32, kk, lane));     // dK[j] = sum_i dS[i][j] Q[i]
+    }
+    store_tile(dqp, p.ldq, p.t, i0, ct * 32, aq, lane);
+    store_tile(dvp, p.ldv, p.t, i0, ct * 32, av, lane);
+    store_tile(dkp, p.ldk, p.t, i0, ct * 32, ak, lane);
+  }
+}
+
+int check(const AttnArgs& a, int dh, int dtype) {
+  if (dtype != 0 || dh != AT) return CDDMSL_ERR_ARG;                 // bf16, head dim 96 (the mapper's geometry)
+  if (a.nseq < 0 || a.t <= 0 || a.t > AT || a.heads <= 0) return CDDMSL_ERR_ARG;
+  if ((a.ldq | a.ldk | a.ldv | a.ldo) & 7) return CDDMSL_ERR_ARG;   // 16-byte rows
+  if ((long)a.nseq * a.heads > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  return CDDMSL_OK;
+}
+
+}  // namespace
+
+extern "C" int cddmsl_attn_small_fwd(const void* q, const void* k, const void* v, void* o, int nseq, int t, int heads, int dh,
+                                     int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream) {
+  AttnArgs a{(const char*)q, (const char*)k, (const char*)v, nullptr, (char*)o, nullptr, nullptr, nullptr,
+             nseq, t, heads, ldq, ldk, ldv, ldo, scale};
+  if (int e = check(a, dh, dtype)) return e;
+  if (nseq == 0) return CDDMSL_OK;
+  hipLaunchKernelGGL(k_attn_small_fwd, dim3((unsigned)(nseq * heads)), dim3(192), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+extern "C" int cddmsl_attn_small_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, void* dk, void* dv,
+                                     int nseq, int t, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale,
+                                     int dtype, void* stream) {
+  AttnArgs a{(const char*)q, (const char*)k, (const char*)v, (const char*)dout, nullptr, (char*)dq, (char*)dk, (char*)dv,
+             nseq, t, heads, ldq, ldk, ldv, ldo, scale};
+  if (int e = check(a, dh, dtype)) return e;
+  if (nseq == 0) return CDDMSL_OK;
+  hipLaunchKernelGGL(k_attn_small_bwd, dim3((unsigned)(nseq * heads)), dim3(192), 0, (hipStream_t)stream, a);
+  return launch_status();
+}

@@ -53,6 +53,8 @@ def _L():
         L.cddmsl_layernorm_bwd.argtypes = [vp] * 6 + [c_long, ci, ci, ci, vp]
         L.cddmsl_focal_ce_fwd.argtypes = [vp] * 4 + [c_long, ci, cf, ci, cf, vp]
         L.cddmsl_focal_ce_bwd.argtypes = [vp] * 5 + [c_long, ci, cf, ci, cf, vp]
+        L.cddmsl_attn_small_fwd.argtypes = [vp] * 4 + [ci] * 8 + [cf, ci, vp]
+        L.cddmsl_attn_small_bwd.argtypes = [vp] * 7 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_contrastive_fwd.argtypes = [vp] * 4 + [ci, ci, vp]
         L.cddmsl_contrastive_bwd.argtypes = [vp] * 5 + [ci, ci, vp]
         _sigs_done = True
@@ -573,6 +575,39 @@ def layernorm_bwd(dy, x, gamma, mean, rstd):
     check(_L().cddmsl_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), R, D, 0, _dt(dy), stream_ptr()),
           "cddmsl_layernorm_bwd")
     return dx
+
+
+def _attn_views(q, kv, t, heads):
+    assert q.dim() == 2 and kv.dim() == 2 and q.is_contiguous() and kv.is_contiguous() and q.dtype == kv.dtype == torch.bfloat16
+    R, d = q.shape
+    assert kv.shape == (R, 2 * d) and R % t == 0 and d % heads == 0
+    return R // t, d, d // heads
+
+
+@_timed("attn_small")
+def attn_small_fwd(q, kv, t, heads, scale):
+    """q [n*t, d], kv [n*t, 2d] (keys | values), bf16 -> o [n*t, d] = softmax(q_h k_h^T * scale) v_h per (sequence, head)"""
+    require_cuda(q, kv)
+    n, d, dh = _attn_views(q, kv, t, heads)
+    o = torch.empty_like(q)
+    vptr = c_void_p(kv.data_ptr() + d * 2)
+    check(_L().cddmsl_attn_small_fwd(ptr(q), ptr(kv), vptr, ptr(o), n, t, heads, dh, d, 2 * d, 2 * d, d, float(scale), 0, stream_ptr()),
+          "cddmsl_attn_small_fwd")
+    return o
+
+
+@_timed("attn_small")
+def attn_small_bwd(q, kv, do, t, heads, scale):
+    """-> (dq [n*t, d], dkv [n*t, 2d]) bf16"""
+    require_cuda(q, kv, do)
+    n, d, dh = _attn_views(q, kv, t, heads)
+    do = do.contiguous()
+    assert do.shape == q.shape and do.dtype == q.dtype
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    vptr, dvptr = c_void_p(kv.data_ptr() + d * 2), c_void_p(dkv.data_ptr() + d * 2)
+    check(_L().cddmsl_attn_small_bwd(ptr(q), ptr(kv), vptr, ptr(do), ptr(dq), ptr(dkv), dvptr, n, t, heads, dh, d, 2 * d, 2 * d, d,
+                                     float(scale), 0, stream_ptr()), "cddmsl_attn_small_bwd")
+    return dq, dkv
 
 
 def focal_ce_fwd(logits, target, gamma, bg_class, bg_weight):

@@ -524,3 +524,25 @@ class MeanPoolFn(torch.autograd.Function):
 
 def mean_pool(x_nhwc):
     return MeanPoolFn.apply(x_nhwc)
+
+
+class SmallAttnFn(torch.autograd.Function):
+    """softmax(QK^T * scale) V of the ClipCap mapper (clipcap.py:59-83) as one fused bf16 MFMA kernel per direction;
+    q [n*t, d], kv [n*t, 2d] are the projection outputs as they come (heads are column blocks, no permutes)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, t, heads, scale):
+        ctx.save_for_backward(q, kv)
+        ctx.cfg = (t, heads, scale)
+        return hip.attn_small_fwd(q, kv, t, heads, scale)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv = ctx.saved_tensors
+        t, heads, scale = ctx.cfg
+        dq, dkv = hip.attn_small_bwd(q, kv, do, t, heads, scale)
+        return dq, dkv, None, None, None
+
+
+def small_attention(q, kv, t, heads, scale):
+    return SmallAttnFn.apply(q, kv, t, heads, scale)

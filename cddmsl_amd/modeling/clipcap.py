@@ -3,8 +3,8 @@
 Only ``TransformerMapper`` is built (``ClipCaptionModel.clip_project``, engine/train_loop.py:281-288); GPT-2 is
 never constructed (it is off the hot path and needs a network fetch).  Parameter names match ``clip_project.*``.
 The linears (31 M + 38 M frozen parameters, 3.13 GMAC/sample) run on the HIP MFMA GEMM with input-gradient only;
-LayerNorm is a fused HIP kernel (f32 residual stream in, GEMM operand out); the 80-token softmax(QK^T)V core is kept on
-torch ops this round ("next").
+LayerNorm is a fused HIP kernel (f32 residual stream in, GEMM operand out); the 80-token softmax(QK^T)V core is one fused
+bf16 MFMA kernel per direction (csrc/attn_small.hip) on the throughput path and fp32 torch ops on the exact-f32 parity path.
 """
 import torch
 import torch.nn.functional as F
@@ -20,10 +20,10 @@ class _Lin(nn.Module):
         self.bias = nn.Parameter(torch.empty(o)) if bias else None
         self._pw = None
 
-    def forward(self, x2d, relu=False):
+    def forward(self, x2d, relu=False, out_f32=True):
         if self._pw is None or self._pw.param is not self.weight:
             self._pw = layers.PreparedWeight(self.weight, None, frozen=True)
-        return layers.linear(x2d, self._pw, self.bias, relu=relu, out_f32=True, train_w=False)
+        return layers.linear(x2d, self._pw, self.bias, relu=relu, out_f32=out_f32, train_w=False)
 
 
 class MlpTransformer(nn.Module):
@@ -79,6 +79,15 @@ class TransformerMapper(nn.Module):
             a = lyr.attn
             H = a.num_heads
             y = layers.layer_norm(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
+            if T == torch.bfloat16 and d // H == 96 and t <= 96:
+                # throughput path: projections emit bf16, one fused attention kernel per direction, heads stay column blocks
+                o = layers.small_attention(a.to_queries(y, out_f32=False), a.to_keys_values(y, out_f32=False), t, H, a.scale)
+                h = h + a.project(o).view(n, t, d)
+                y = layers.layer_norm(h.view(n * t, d), lyr.norm2.weight, lyr.norm2.bias, T)
+                y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True).to(T))
+                h = h + y.view(n, t, d)
+                continue
+            # exact-f32 parity path: the same arithmetic on torch ops (the fused kernel is bf16-only)
             q = a.to_queries(y).view(n, t, H, d // H).permute(0, 2, 1, 3)
             kv = a.to_keys_values(y).view(n, t, 2, H, d // H)
             k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)

@@ -78,6 +78,14 @@ int cddmsl_iou_match(const float* gt, int G, const float* preds, int P, long* ma
 int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int TP, int C, int dtype, void* stream);
 int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, int TP, int C, int dtype, void* stream);
 
+/* ---- fused multi-head attention for short sequences: the ClipCap mapper's softmax(QK^T * scale) V (no mask), 80 tokens x 8
+ * heads of 96 (modeling/backbone/clipcap/clipcap.py:59-83).  bf16 only (dtype 0), dh == 96, t <= 96; element (s, i, h, c) of
+ * q / k / v / o sits at ((s*t + i) * ld + h*dh + c); the backward recomputes the probabilities from q, k. */
+int cddmsl_attn_small_fwd(const void* q, const void* k, const void* v, void* o, int nseq, int t, int heads, int dh, int ldq,
+                          int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+int cddmsl_attn_small_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, void* dk, void* dv, int nseq,
+                          int t, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+
 /* ---- fp32 heads: cosine-logit classifier (modeling/roi_heads/fast_rcnn.py:546-572) and the contrastive loss over
  * the cosine-similarity matrix (modeling/meta_arch/rcnn.py:308-317,458-468) ------------------------------------ */
 int cddmsl_l2norm_fwd(const float* x, float* y, float* inv, long R, int D, float eps, void* stream);

@@ -267,3 +267,29 @@ def test_layernorm_and_focal_ce():
     l.backward()
     assert abs(float(l) - float(ref_l)) < 1e-5 * abs(float(ref_l))
     assert (sg.grad.cpu() - s.grad).abs().max() < 1e-5 * float(s.grad.abs().max()) + 1e-9
+
+
+@pytest.mark.parametrize("n,t", [(3, 80), (2, 96), (5, 37)])
+def test_small_attention_fwd_bwd(n, t):
+    """Fused mapper attention (csrc/attn_small.hip, bf16 MFMA + fp32 softmax) vs fp32 torch on the same bf16 inputs
+    (clipcap.py:59-83: softmax(q k^T * scale) v per head, no mask)."""
+    from cddmsl_amd import layers
+    H, dh = 8, 96
+    d = H * dh
+    g = torch.Generator().manual_seed(7)
+    q = (torch.randn(n * t, d, generator=g) * 0.5).bfloat16()
+    kv = (torch.randn(n * t, 2 * d, generator=g) * 0.5).bfloat16()
+    do = torch.randn(n * t, d, generator=g).bfloat16()
+    scale = dh ** -0.5
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    qq = qr.view(n, t, H, dh).permute(0, 2, 1, 3)
+    kk = kvr[:, :d].reshape(n, t, H, dh).permute(0, 2, 1, 3)
+    vv = kvr[:, d:].reshape(n, t, H, dh).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) * scale, dim=-1) @ vv).permute(0, 2, 1, 3).reshape(n * t, d)
+    ref.backward(do.float())
+    qg, kvg = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    o = layers.small_attention(qg, kvg, t, H, scale)
+    o.backward(do.cuda())
+    for got, want, name in ((o, ref, "o"), (qg.grad, qr.grad, "dq"), (kvg.grad, kvr.grad, "dkv")):
+        err = (got.float().cpu() - want.detach()).abs().max() / want.detach().abs().max()
+        assert err < 2e-2, (name, float(err))
