@@ -1570,7 +1570,7 @@ static bool use_gemm256(const ConvArgs& a) {
   if (2 * a.pad > a.KH - 1 || 2 * a.pad > a.KW - 1) return false;   // rows of a tile must ascend in memory (per-block buffer base)
   if (mode == 2) return true;                                   // forced (tests)
   const long tiles = (long)((a.M + 255) / 256) * (a.Cout / 256) * g_batch_peek();
-  return tiles >= 224 && a.Kc >= 32;
+  return tiles >= 224;
 }
 
 

@@ -228,8 +228,9 @@ class RPN(nn.Module):
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
 
     @torch.no_grad()
-    def predict_proposals(self, logits, deltas, image_sizes, hf, wf):
-        """rpn.py:482-533 + find_top_rpn_proposals proposal_utils.py:22-130 for all images at once."""
+    def predict_proposals(self, logits, deltas, image_sizes, hf, wf, defer=False):
+        """rpn.py:482-533 + find_top_rpn_proposals proposal_utils.py:22-130 for all images at once.
+        ``defer=True`` returns a closure that takes the stage's one host sync and builds the Instances."""
         N, total = logits.shape
         training = self.training
         topk = min(total, self.pre_nms_topk[training])
@@ -241,17 +242,22 @@ class RPN(nn.Module):
         post = self.post_nms_topk[training]
         keep, nkeep = hip.nms(boxes, valid, self.nms_thresh, post)
         bad = (valid == 2).any() | ~torch.isfinite(keys[:, :topk]).all()
-        host = torch.cat([nkeep, bad.to(torch.int32).view(1)]).tolist()      # the one host sync of this stage
-        if host[-1] and training:
-            raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")  # proposal_utils.py:100-105
-        out = []
-        for n in range(N):
-            k = keep[n, : host[n]].long()
-            inst = Instances(tuple(image_sizes[n]))
-            inst.proposal_boxes = Boxes(boxes[n][k])
-            inst.objectness_logits = keys[n][k]
-            out.append(inst)
-        return out
+        flags = torch.cat([nkeep, bad.to(torch.int32).view(1)])
+
+        def finish():
+            host = flags.tolist()                                            # the one host sync of this stage
+            if host[-1] and training:
+                raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")  # proposal_utils.py:100-105
+            out = []
+            for n in range(N):
+                k = keep[n, : host[n]].long()
+                inst = Instances(tuple(image_sizes[n]))
+                inst.proposal_boxes = Boxes(boxes[n][k])
+                inst.objectness_logits = keys[n][k]
+                out.append(inst)
+            return out
+
+        return finish if defer else finish()
 
     def forward_nhwc(self, image_sizes, res4, gt_instances=None):
         N, hf, wf, _ = res4.shape
@@ -259,13 +265,17 @@ class RPN(nn.Module):
         lg = logits.reshape(N, -1)                # (N, Hi*Wi*A)   rpn.py:456-460
         dl = deltas.reshape(N, -1, 4)             # (N, Hi*Wi*A, 4) rpn.py:461-467 (NHWC already has (h,w,a,b) order)
         losses = {}
+        # The proposal stage (sort, decode, NMS: milliseconds of device work, no random draws) is ENQUEUED before the anchor
+        # sampling, whose host side (one D2H sync, then a CPU randperm per image over ~60 k negatives) would otherwise
+        # leave the device idle; its own host sync (the keep counts) is taken afterwards.  Results are unchanged: the two
+        # stages are independent (rpn.py:469-480 runs them in the other order).
+        finish = self.predict_proposals(lg, dl, image_sizes, hf, wf, defer=True)
         if self.training:
             assert gt_instances is not None, "RPN requires gt_instances in training!"
             anchors = self.anchor_generator.grid(hf, wf)
             labels, matched = self.label_and_sample_anchors(anchors, gt_instances)
             losses = self.losses(anchors, lg, labels, dl, matched)
-        proposals = self.predict_proposals(lg, dl, image_sizes, hf, wf)
-        return proposals, losses
+        return finish(), losses
 
     def forward(self, images, features, gt_instances=None):
         """rpn.py:431-480.  ``images`` needs ``.image_sizes``; features: dict of logical-NCHW maps."""
