@@ -1218,6 +1218,7 @@ __global__ void k_weight_prep(const float* w, const float* scale, char* wf, char
   }
 }
 
+static thread_local int g_last_kernel = 0;   // which kernel the last conv/GEMM entry point of this thread launched (cddmsl_last_kernel)
 static thread_local int g_batch = 1;   // set by the batched entry point around its launch
 static inline int g_batch_peek() { return g_batch; }
 
@@ -1581,16 +1582,19 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   if (use_gemm256(a)) {
     grid = (long)(a.Cout / 256) * ((a.M + 255) / 256);
+    g_last_kernel = 3;
     if (a.KH == 1 && a.KW == 1 && a.pad == 0)
       hipLaunchKernelGGL((k_conv_fwd256<T, false>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
     else
       hipLaunchKernelGGL((k_conv_fwd256<T, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
-  } else if (a.pool) hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid, (unsigned)g_batch), dim3(256), 0, st, a);
+  } else if (a.pool) { g_last_kernel = 2; hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a); }
+  else { g_last_kernel = 1; hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid, (unsigned)g_batch), dim3(256), 0, st, a); }
   return launch_status();
 }
 
 }  // namespace
+
+extern "C" int cddmsl_last_kernel(void) { return g_last_kernel; }
 
 extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias,
                                const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin,
@@ -1681,11 +1685,13 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
     a.mtiles_per_split = (int)((total_mt + sp - 1) / sp);
     sp = (total_mt + a.mtiles_per_split - 1) / a.mtiles_per_split;
     if (wgrad256_span_ok(a)) {
+      g_last_kernel = 6;
       hipLaunchKernelGGL(k_wgrad256, dim3((unsigned)(tiles2 * sp)), dim3(512), 0, (hipStream_t)stream, a);
       return launch_status();
     }
     a.mtiles_per_split = keep;
   }
+  g_last_kernel = same ? 5 : 4;
   if (same) {
     if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -1750,6 +1756,7 @@ extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, i
   splits = (total_mt + p.mtiles_per_split - 1) / p.mtiles_per_split;
   long grid = tiles * splits;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  g_last_kernel = 5;
   if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();

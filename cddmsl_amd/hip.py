@@ -20,6 +20,7 @@ def _L():
     L = lib()
     if not _sigs_done:
         vp, ci, cf = c_void_p, c_int, c_float
+        L.cddmsl_last_kernel.argtypes = []
         L.cddmsl_conv_fwd.argtypes = [vp] * 7 + [ci] * 16 + [vp]
         L.cddmsl_conv_wgrad.argtypes = [vp] * 4 + [ci] * 12 + [vp]
         L.cddmsl_weight_prep.argtypes = [vp] * 4 + [ci] * 5 + [vp]
@@ -114,6 +115,8 @@ class _Profiler:
 
 
 PROFILE = _Profiler()
+# cddmsl_last_kernel() ids -> profiler row names (one row per KERNEL, so the roofline object describes one kernel)
+_CONV_KERNEL = {1: "k_conv_fwd", 2: "k_conv_fwd_reg", 3: "k_conv_fwd256", 4: "k_conv_wgrad", 5: "k_conv_wgrad_dma", 6: "k_wgrad256"}
 
 
 def _timed(name):
@@ -159,7 +162,8 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
                               N, H, W, Cin, Cout, KH, KW, stride, pad, int(pool), Cout, Cout, Cout,
                               int(relu), int(out_f32), _dt(x), stream_ptr())
     check(st, "cddmsl_conv_fwd")
-    PROFILE.end(e0, "conv_fwd", 2.0 * N * Ho * Wo * Cout * KH * KW * Cin,    # algorithmic 2*M*N*K
+    PROFILE.end(e0, _CONV_KERNEL.get(_L().cddmsl_last_kernel(), "conv_fwd") if e0 is not None else "conv_fwd",
+                2.0 * N * Ho * Wo * Cout * KH * KW * Cin,    # algorithmic 2*M*N*K
                 (N * Ho * Wo, Cout, KH * KW * Cin, KH, int(pool), stride),
                 # algorithmic HBM bytes: every operand once
                 nbytes=float(x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()
@@ -192,7 +196,8 @@ def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None
     st = _L().cddmsl_conv_wgrad(ptr(x), ptr(dy), ptr(out), ptr(scale), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                 int(pool), Cout, _dt(x), stream_ptr())
     check(st, "cddmsl_conv_wgrad")
-    PROFILE.end(e0, "conv_wgrad", 2.0 * (dy.numel() // Cout) * Cout * KH * KW * Cin,
+    PROFILE.end(e0, _CONV_KERNEL.get(_L().cddmsl_last_kernel(), "conv_wgrad") if e0 is not None else "conv_wgrad",
+                2.0 * (dy.numel() // Cout) * Cout * KH * KW * Cin,
                 (dy.numel() // Cout, Cout, KH * KW * Cin, KH, int(pool), stride))
     return out
 

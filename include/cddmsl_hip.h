@@ -6,7 +6,8 @@
  * file csrc/vision.cpp is absent from the tree) and through torchvision/ATen for the hot path.  This header is
  * the plain-C equivalent: device pointers + sizes + the HIP stream to enqueue on, no torch types.  Every function
  * returns 0 on success (1 = bad argument, 2 = launch failure), never synchronises, owns no memory (the caller
- * allocates outputs and workspaces) and keeps no global mutable state, so calls are re-entrant and stream-ordered.
+ * allocates outputs and workspaces) and keeps no global mutable state (one thread-local diagnostic id excepted, see
+ * cddmsl_last_kernel), so calls are re-entrant and stream-ordered.
  *
  * Conventions
  *   dtype      0 = bf16 (throughput path), 1 = f32 (exact-f32 MFMA parity path)
@@ -46,6 +47,10 @@ int cddmsl_gemm_nt_batched(const void* a, const void* w, void* c, const float* b
                            int batch, long sa, long sw, long sc, int out_f32, int dtype, void* stream);
 int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, int M, int N, int K, int lda, int ldb, int ldo, int batch, long sa,
                            long sb, long so, int mode, int dtype, void* stream);
+/* diagnostic: the kernel the calling thread's last conv / GEMM entry point launched -- 1 k_conv_fwd (128x128 LDS-DMA),
+ * 2 k_conv_fwd_reg (fused avg-pool loader), 3 k_conv_fwd256 (256x256 ping-pong), 4 k_conv_wgrad, 5 k_conv_wgrad_dma,
+ * 6 k_wgrad256.  bench.py uses it to attribute HIP-event times to kernels. */
+int cddmsl_last_kernel(void);
 /* f32 master -> `dtype` forward weights and flipped/transposed dgrad weights scaled by the FrozenBN scale */
 int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int Cout, int KH, int KW, int Cin,
                        int dtype, void* stream);

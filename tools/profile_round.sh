@@ -27,7 +27,7 @@ def per_launch(tag, counter, kern):
             tot += float(r['Counter_Value']); ids.add(r['Dispatch_Id'])
     return tot / max(len(ids), 1), len(ids)
 out = {}
-for kern, name in (("k_conv_fwdI", "k_conv_fwd"), ("k_conv_wgrad_dma", "k_conv_wgrad_dma")):
+for kern, name in (("k_conv_fwd256", "k_conv_fwd256"), ("k_conv_fwdI", "k_conv_fwd"), ("k_wgrad256", "k_wgrad256"), ("k_conv_wgrad_dma", "k_conv_wgrad_dma")):
     fk, n1 = per_launch("fetch", "FETCH_SIZE", kern)      # KiB per launch
     wk, n2 = per_launch("write", "WRITE_SIZE", kern)
     out[name] = {"launches_sampled": n1, "fetch_size_kib_raw": fk, "write_size_kib": wk,
