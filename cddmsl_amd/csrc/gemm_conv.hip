@@ -966,6 +966,122 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_dma(WgradArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Streaming batched TN GEMM for SHORT reductions (the attention pool's per-region products: 56 or 64 reduction rows,
+// thousands of regions): out_b[n][k] = sum_m A_b[m][n] B_b[m][k].  One block = one (n-tile, k-tile) column of outputs
+// for a RUN of batches: the double-buffered LDS-DMA pipeline of k_conv_wgrad_dma keeps running across batch boundaries
+// (the next batch's tile is in flight while this one is reduced and stored), where one-block-per-batch launches paid a
+// full global-memory latency per 32 KiB tile.  Same LDS images, swizzle and transposed reads as k_conv_wgrad_dma.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_stream(WgradArgs p, int nbatch, int bpb) {
+  constexpr int ES = Mma<T>::ES;
+  constexpr int COLS = 256 / ES;
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][WM * 16];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ntk = (p.K + COLS - 1) / COLS;
+  const int tile_k = blockIdx.x % ntk, tile_n = blockIdx.x / ntk;
+  const int n0 = tile_n * COLS, k0 = tile_k * COLS;
+  const int b0 = blockIdx.y * bpb, nb = min(bpb, nbatch - b0);
+  const int nmt = (p.M + WM - 1) / WM;
+  const int nit = nb * nmt;
+
+  const int cc = t & 15, rb = t >> 4;
+  const int cl = cc ^ fsw(rb);
+  const int kc = k0 * ES / 16 + cl, nc = n0 * ES / 16 + cl;
+  const bool vk = kc < p.Kc, vn = nc < p.ncc;
+  const char* zp = (const char*)g_zero_page;
+  int sb = 0, smt = 0;                               // (batch, reduction tile) of the next tile to stage
+  auto stage = [&](int buf) {
+    const char* db = p.dy + (long)(b0 + sb) * p.bd + (long)nc * 16;
+    const char* xb = p.x + (long)(b0 + sb) * p.bx + (long)kc * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = smt * WM + rb + 16 * i;
+      const bool vm = m < p.M;
+      glds16((vm && vn) ? db + ((long)m * p.ldd) * ES : zp, &lds[buf][0][(4 * wvu + 16 * i) * 16]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = smt * WM + rb + 16 * i;
+      const bool vm = m < p.M;
+      glds16((vm && vk) ? xb + ((long)m * p.xrs) * 16 : zp, &lds[buf][1][(4 * wvu + 16 * i) * 16]);
+    }
+    if (++smt == nmt) { smt = 0; ++sb; }
+  };
+
+  constexpr int WT = COLS / 2;
+  constexpr int NT = WT / 32;
+  const int wn = wv >> 1, wk = wv & 1;
+  f32x16 acc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  typename TrFragS<T>::Off offa[NT], offb[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    offa[i] = TrFragS<T>::prep(wn * WT + i * 32, lane);
+    offb[i] = TrFragS<T>::prep(wk * WT + i * 32, lane);
+  }
+  const int r = lane & 31, h = lane >> 5;
+
+  if (nit > 0) stage(0);
+  int cb = 0, cmt = 0;                               // (batch, reduction tile) being reduced
+  for (int it = 0; it < nit; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < nit) {
+      stage(cur ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ms = 0; ms < WM; ms += TrFragS<T>::MSTEP) {
+      u32x4 fa[NT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        fa[i] = TrFragS<T>::read(lds[cur][0], ms, offa[i]);
+        fb[i] = TrFragS<T>::read(lds[cur][1], ms, offb[i]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) Mma<T>::step(acc[a][b], fa[a], fb[b]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (++cmt == nmt) {                              // batch complete: store its tile (the next batch's DMA is already in flight)
+      char* outp = (char*)p.dw + (long)(b0 + cb) * p.bo;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          const int k = k0 + wk * WT + b * 32 + r;
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int n = n0 + wn * WT + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            if (k < p.K && n < p.Cout) {
+              const float v = acc[a][b][g];
+              const long o = (long)n * p.ldo + k;
+              if (p.direct == 0) atomicAdd((float*)outp + o, v);
+              else if (p.direct == 1) ((float*)outp)[o] = v;
+              else Mma<T>::store(outp + o * ES, v);
+            }
+            acc[a][b][g] = 0.f;
+          }
+        }
+      cmt = 0; ++cb;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad / TN GEMM on the 256x256 ping-pong structure of k_conv_fwd256 (bf16): output tile 256 n x 256 k, reduction
 // tiles of 64 m rows, 8 waves (2 over n x 4 over k; 128 n x 64 k per wave), the two wave groups one barrier apart.
 // Operands stay row-major in LDS ([64 rows][256 B] images, chunk ^= fsw(row)) and are read transposed
@@ -1751,6 +1867,17 @@ extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, i
     long maxs = (total_mt + 7) / 8;
     splits = want < 1 ? 1 : (want > maxs ? maxs : want);
     if (splits < 1) splits = 1;
+  }
+  if (total_mt <= 4 && batch >= 64) {
+    // short reductions over many batches: stream runs of batches through one block (k_gemm_tn_stream)
+    long bpb = (tiles * batch + 4095) / 4096, minb = (8 + total_mt - 1) / total_mt;
+    if (bpb < minb) bpb = minb;
+    if (bpb > batch) bpb = batch;
+    const unsigned gy = (unsigned)((batch + bpb - 1) / bpb);
+    g_last_kernel = 7;
+    if (dtype == 0) hipLaunchKernelGGL(k_gemm_tn_stream<__bf16>, dim3((unsigned)tiles, gy), dim3(256), 0, (hipStream_t)stream, p, batch, (int)bpb);
+    else hipLaunchKernelGGL(k_gemm_tn_stream<float>, dim3((unsigned)tiles, gy), dim3(256), 0, (hipStream_t)stream, p, batch, (int)bpb);
+    return launch_status();
   }
   p.mtiles_per_split = (int)((total_mt + splits - 1) / splits);
   splits = (total_mt + p.mtiles_per_split - 1) / p.mtiles_per_split;

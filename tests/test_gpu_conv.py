@@ -133,6 +133,15 @@ def test_batched_gemms(dtype, tol):
     hip.gemm_tn_batched(Pm.cuda(), Tk.cuda(), Z, 56, 32, 128, 32, 128, 128, B, 56 * 32, 56 * 128, 32 * 128)
     ref = torch.bmm(Pm.float().transpose(1, 2), Tk.float())
     assert (Z.float().cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    # the same product over many "regions" runs on the streaming kernel (runs of batches per block, DMA pipeline
+    # carried across batch boundaries): 203 batches (ragged last run), 56-row and 100-row (two tiles) reductions
+    for Bn, Mm in ((203, 56), (77, 100)):
+        Pm = torch.randn(Bn, Mm, 32, generator=g).to(dtype)
+        Tn = torch.randn(Bn, Mm, 256, generator=g).to(dtype)
+        Z = torch.zeros(Bn, 32, 256, dtype=dtype).cuda()
+        hip.gemm_tn_batched(Pm.cuda(), Tn.cuda(), Z, Mm, 32, 256, 32, 256, 256, Bn, Mm * 32, Mm * 256, 32 * 256)
+        ref = torch.bmm(Pm.float().transpose(1, 2), Tn.float())
+        assert (Z.float().cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
     # TN accumulate (f32 atomics, many row tiles, split over blocks): dW[h] += A[:, h]^T @ X[:, h]
     Mr = 1500
     Ar = torch.randn(Mr, Hh * 64, generator=g).to(dtype)
