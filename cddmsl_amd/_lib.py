@@ -34,8 +34,16 @@ def lib():
 
 
 def stream_ptr():
-    """The HIP stream torch is currently enqueuing on, as a void*."""
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The HIP stream torch is currently enqueuing on, as a void* (raw-stream query: ~1 us, this runs once per launch)."""
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+
+
+def to_device_async(cpu_tensor, device):
+    """Host -> device copy that does NOT synchronise: staged through pinned memory and enqueued on the current stream
+    (a pageable ``.to(device)`` blocks until everything already queued has run, i.e. acts as a full device sync)."""
+    if cpu_tensor.numel() == 0:
+        return torch.empty(cpu_tensor.shape, dtype=cpu_tensor.dtype, device=device)
+    return cpu_tensor.pin_memory().to(device, non_blocking=True)
 
 
 def ptr(t):

@@ -14,6 +14,7 @@ import torch.distributed as dist
 from torch import nn
 
 from .. import hip, layers
+from .._lib import to_device_async
 from ..registry import META_ARCH_REGISTRY
 from ..structures import ImageList, as_instances
 from . import resnet  # noqa: F401  (registers build_resnet_backbone)
@@ -170,7 +171,9 @@ class GeneralizedRCNN(nn.Module):
                     f = torch.cat([shared["res4"], f])
                     self.proposal_generator.replay_sampling_draws(shared["counts"])
                     props = shared["proposals"]
-                sel = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image].to(self.device) for p in props]
+                sel_cpu = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image] for p in props]
+                sel_dev = to_device_async(torch.cat(sel_cpu), self.device)      # one pinned, non-blocking H2D for all images
+                sel = torch.split(sel_dev, [len(s_) for s_ in sel_cpu])
                 props = [p[s] for p, s in zip(props, sel)]
             rs, rt = self.roi_heads.forward_get_features_paired(f, n, props, self.backbone.layer4, self.backbone.attnpool)
             e = self.project(v2l(torch.cat([rs, rt]), clipcap_model))

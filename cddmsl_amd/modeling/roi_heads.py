@@ -13,6 +13,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import hip, layers
+from .._lib import to_device_async
 from ..registry import ROI_HEADS_REGISTRY
 from ..structures import Boxes, Instances, ShapeSpec, as_instances
 from .backbone import to_nhwc, to_nchw
@@ -35,7 +36,7 @@ class ROIPooler(nn.Module):
         # convert_boxes_to_pooler_format poolers.py:68-95: rois grouped by image, (batch_idx, x0, y0, x1, y1)
         rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i), device=dev), b.tensor.float()], dim=1)
                           for i, b in enumerate(box_lists)], dim=0).contiguous()
-        start = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+        start = to_device_async(torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32), dev)
         return layers.roi_align(feat, rois, start, self.output_size, self.scale, self.sampling_ratio, True)
 
     def forward(self, x, box_lists):
@@ -118,7 +119,16 @@ class FastRCNNOutputLayers(nn.Module):
         gboxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
         self._log_stats(scores.detach(), gt_classes)
         loss_cls = layers.focal_cross_entropy(scores, gt_classes, self.focal_scaled_loss, self.num_classes, self.bg_cls_loss_weight)
-        fg = torch.nonzero((gt_classes >= 0) & (gt_classes < self.num_classes), as_tuple=True)[0]
+        if all(getattr(p, "_num_fg", None) is not None for p in proposals):
+            # sampled proposals list their foreground picks first (roi_heads.py:211-234): the index list is known on the
+            # host, no nonzero / device sync (fast_rcnn.py:653 takes nonzero of the same mask)
+            offs, idx = 0, []
+            for p in proposals:
+                idx.append(torch.arange(offs, offs + p._num_fg))
+                offs += len(p)
+            fg = to_device_async(torch.cat(idx), gt_classes.device)
+        else:
+            fg = torch.nonzero((gt_classes >= 0) & (gt_classes < self.num_classes), as_tuple=True)[0]
         fg_pred = deltas.view(-1, self.num_classes, 4)[fg, gt_classes[fg]]
         gt_d = get_deltas(pboxes[fg], gboxes[fg], self.box_weights)
         loss_box = torch.abs(fg_pred - gt_d).sum() / max(gt_classes.numel(), 1.0)
@@ -186,6 +196,7 @@ class CLIPRes5ROIHeads(nn.Module):
             inst.proposal_boxes, inst.objectness_logits, inst.gt_classes = Boxes(boxes[sidx]), logits[sidx], cls[sidx]
             if gtc.numel() > 0:
                 inst.gt_boxes = Boxes(gtb[midx[sidx]])
+            inst._num_fg = int(fg.numel())      # host-side: the first _num_fg rows are the foreground samples
             nfg.append(fg.numel())
             nbg.append(bg.numel())
             out.append(inst)

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import hip, layers
+from .._lib import to_device_async
 from ..registry import ANCHOR_GENERATOR_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY
 from ..structures import Boxes, Instances, as_instances
 from .backbone import to_nhwc, to_nchw
@@ -45,17 +46,21 @@ def subsample_labels(labels, num_samples, positive_fraction, bg_label, gen):
 
 
 def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_label, gen, counts_out=None):
-    """``subsample_labels`` for a list of per-image label vectors with TWO device->host syncs in total instead of two per
-    image: one nonzero over the concatenated positives, one over the negatives; the per-image permutations are then drawn
-    on the host in the reference's order (image by image: positives, negatives -- sampling.py:47-48)."""
+    """``subsample_labels`` for a list of per-image label vectors with ONE device->host sync in total instead of two per
+    image (the per-image positive / negative counts); the per-image permutations are then drawn on the host in the
+    reference's order (image by image: positives, negatives -- sampling.py:47-48) and shipped back in one async copy."""
     lens = [int(l.numel()) for l in label_list]
     cat = torch.cat(label_list)
-    pos_all = torch.nonzero((cat != -1) & (cat != bg_label), as_tuple=True)[0]
-    neg_all = torch.nonzero(cat == bg_label, as_tuple=True)[0]
+    pmask, nmask = (cat != -1) & (cat != bg_label), cat == bg_label
     offs = torch.tensor([0] + lens).cumsum(0)
-    bounds = offs.to(cat.device)
-    # per-image counts from the sorted index lists (one small D2H copy)
-    cnt = torch.stack([torch.searchsorted(pos_all, bounds), torch.searchsorted(neg_all, bounds)]).cpu()
+    # per-image counts: cumulative sums sampled at the image boundaries -> ONE small D2H copy (the stage's only sync);
+    # the index lists then have a known size (nonzero_static), so building them does not sync again
+    cs = torch.stack([pmask.cumsum(0), nmask.cumsum(0)])
+    ends = to_device_async((offs[1:] - 1).clamp(min=0), cat.device)
+    cnt_end = cs[:, ends].cpu() * (offs[1:] > 0)            # (an empty leading image has no last element to sample)
+    cnt = torch.cat([torch.zeros(2, 1, dtype=cnt_end.dtype), cnt_end], dim=1)
+    pos_all = torch.nonzero_static(pmask, size=int(cnt[0, -1]))[:, 0]
+    neg_all = torch.nonzero_static(nmask, size=int(cnt[1, -1]))[:, 0]
     out = []
     for i in range(len(label_list)):
         p0, p1 = int(cnt[0, i]), int(cnt[0, i + 1])
@@ -68,9 +73,10 @@ def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_labe
         perm1 = torch.randperm(npos, generator=gen)[:num_pos]
         perm2 = torch.randperm(nneg, generator=gen)[:num_neg]
         out.append((perm1 + p0, perm2 + n0, int(offs[i])))
-    # one H2D copy for all index lists
-    sel_pos = torch.cat([o[0] for o in out]).to(cat.device)
-    sel_neg = torch.cat([o[1] for o in out]).to(cat.device)
+    # one (asynchronous, pinned) H2D copy for all index lists
+    sel = to_device_async(torch.cat([o[0] for o in out] + [o[1] for o in out]), cat.device)
+    npos_sel = sum(len(o[0]) for o in out)
+    sel_pos, sel_neg = sel[:npos_sel], sel[npos_sel:]
     pos_idx, neg_idx = pos_all[sel_pos], neg_all[sel_neg]
     res, a, b = [], 0, 0
     for (p, n, off) in out:
@@ -201,6 +207,7 @@ class RPN(nn.Module):
             lab.fill_(-1)
             lab[pos] = 1
             lab[neg] = 0
+        self.last_pos = [pos for pos, _ in picks]
         return labels, matched
 
     def replay_sampling_draws(self, counts):
@@ -218,7 +225,9 @@ class RPN(nn.Module):
         pos = gl == 1
         self.storage["rpn/num_pos_anchors"] = pos.sum() / n
         self.storage["rpn/num_neg_anchors"] = (gl == 0).sum() / n
-        pi = torch.nonzero(pos, as_tuple=True)
+        # positives = the sampled foreground picks (known index lists): no nonzero, hence no host sync here
+        img_of = torch.repeat_interleave(torch.arange(n), torch.tensor([len(pk) for pk in self.last_pos]))
+        pi = (to_device_async(img_of, gl.device), torch.cat(self.last_pos))
         gt_d = get_deltas(anchors[pi[1]], torch.stack(matched)[pi], self.weights)
         loc = torch.abs(deltas[pi] - gt_d).sum()
         valid = gl >= 0
@@ -235,7 +244,7 @@ class RPN(nn.Module):
         training = self.training
         topk = min(total, self.pre_nms_topk[training])
         keys, order = hip.sort_desc(logits.detach().contiguous())
-        img_hw = torch.tensor(image_sizes, dtype=torch.int32, device=logits.device)
+        img_hw = to_device_async(torch.tensor(image_sizes, dtype=torch.int32), logits.device)
         ag = self.anchor_generator
         boxes, valid = hip.rpn_decode(order, deltas.detach().contiguous(), ag.cell_anchors_0, img_hw, hf, wf, topk,
                                       float(ag.strides[0]), ag.offset, self.weights, SCALE_CLAMP, self.min_box_size)
