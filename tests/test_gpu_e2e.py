@@ -45,11 +45,13 @@ def _oracle_cfg(cfg, kd):
                   rpn_post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, kd_regularization=kd)
 
 
-@pytest.mark.parametrize("kd,share", [(False, True), (True, True), (True, False)])
-def test_step_losses_and_grads_match_oracle(kd, share):
+@pytest.mark.parametrize("kd,share,gemm256", [(False, True, "1"), (True, True, "1"), (True, False, "1"), (False, True, "2")])
+def test_step_losses_and_grads_match_oracle(kd, share, gemm256, monkeypatch):
     """share=True: the region-level branch reuses the supervised pass's source-image res4 + RPN proposals (engine.py /
     rcnn.py notes); share=False: every branch recomputes, as the reference does.  Both must match the oracle, which
-    always recomputes."""
+    always recomputes.  gemm256="2" forces every eligible layer onto the 256x256 ping-pong kernel (its f32 instantiation),
+    which the size heuristic would not pick at this test's small shapes."""
+    monkeypatch.setenv("CDDMSL_GEMM256", gemm256)
     from cddmsl_amd import synthetic
     from cddmsl_amd.engine import SimpleTrainer
     from cddmsl_amd.solver import build_optimizer
@@ -88,9 +90,12 @@ def test_step_losses_and_grads_match_oracle(kd, share):
     print("losses", got, "worst grad rel err", worst)
 
 
-def test_bf16_step_runs_and_is_close():
+@pytest.mark.parametrize("gemm256", ["1", "2"])
+def test_bf16_step_runs_and_is_close(gemm256, monkeypatch):
     """Throughput path (bf16 MFMA, fp32 accumulate): finite losses, loosely near the f32 oracle values (bf16 has
-    8 significant bits; index stages may pick different RoIs, so this is a sanity bound, not the parity gate)."""
+    8 significant bits; index stages may pick different RoIs, so this is a sanity bound, not the parity gate).
+    gemm256="2": the whole step on the 256x256 forward and weight-gradient kernels wherever they are legal."""
+    monkeypatch.setenv("CDDMSL_GEMM256", gemm256)
     from cddmsl_amd import synthetic
     from cddmsl_amd.engine import SimpleTrainer
     from cddmsl_amd.solver import build_optimizer
