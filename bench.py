@@ -105,6 +105,21 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = hip.PROFILE.collect()
+    # RN50-C4 supervised FORWARD alone (backbone to res4, RPN, RoIAlign, RoI layer4, attention pool, classifier, losses), the
+    # quantity BASELINE.json's roofline target is stated on: algorithmic 1.878 TFLOP per 800x1333 image (SURVEY.md 8(d):
+    # 938.8 GMAC, query-0-only attention pool), timed outside the step timing above, rank 0's own clock
+    fwd_ms = None
+    if rank == 0 and (args.height, args.width) == (800, 1333):
+        data = next(tr._data_loader_iter)
+        tr.model.share_source_pass = False
+        for _ in range(2):
+            tr.model(data)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(5):
+            tr.model(data)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - tf0) / 5 * 1e3
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -145,6 +160,11 @@ def main():
             "kernels_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["ms"] > 0 and v["flops"] > 0},
             "losses": losses,
         }
+        if fwd_ms is not None:
+            ftf = 1.878 * args.batch
+            out["forward_roofline"] = {"what": "supervised RN50-C4 forward only (autograd recording on), algorithmic 1.878 TFLOP/image",
+                                       "ms": fwd_ms, "achieved": ftf / (fwd_ms * 1e-3), "peak": peak, "unit": "TFLOP/s",
+                                       "frac": ftf / (fwd_ms * 1e-3) / peak, "images_per_sec_forward": args.batch / (fwd_ms * 1e-3)}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
             out["cpu_baseline"] = cpu_baseline(args.height, args.width, threads)
