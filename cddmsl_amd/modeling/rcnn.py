@@ -20,6 +20,7 @@ from ..structures import ImageList, as_instances
 from . import resnet  # noqa: F401  (registers build_resnet_backbone)
 from .backbone import build_backbone, to_nchw
 from .clipcap import v2l
+from .postprocessing import detector_postprocess
 from .roi_heads import build_roi_heads
 from .rpn import build_proposal_generator
 
@@ -144,8 +145,32 @@ class GeneralizedRCNN(nn.Module):
         return layers.contrastive_loss(ft, fs), kd_loss
 
     # ------------------------------------------------------------------ forward
+    # ------------------------------------------------------------------ inference (rcnn.py:690-784)
+    @torch.no_grad()
+    def inference(self, batched_inputs: List[Dict], detected_instances=None, do_postprocess: bool = True):
+        assert not self.training
+        images, sizes = self.preprocess_image(batched_inputs, "image")
+        res4 = self.backbone.forward_nhwc(images, want_res5=False)["res4"]
+        feats = {"res4": to_nchw(res4)}
+        if detected_instances is None:
+            proposals, _ = self.proposal_generator.forward_nhwc(sizes, res4, None)
+            kw = dict(res5=self.backbone.layer4, attnpool=self.backbone.attnpool) if self.use_clip_c4 else {}
+            results, _ = self.roi_heads(ImageList(None, sizes), feats, proposals, None, **kw)
+        else:
+            results = self.roi_heads.forward_with_given_boxes(feats, [x.to(self.device) for x in detected_instances])
+        return self._postprocess(results, batched_inputs, sizes) if do_postprocess else results
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes):
+        """rcnn.py:770-784: rescale to the dataset dict's original ``height`` / ``width``"""
+        out = []
+        for res, inp, size in zip(instances, batched_inputs, image_sizes):
+            out.append({"instances": detector_postprocess(res, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return out
+
     def forward(self, batched_inputs: List[Dict], clipcap_model=None, branch="supervised", KD_regularization=True):
-        assert self.training, "inference is a 'next' row (SURVEY.md 8(f))"
+        if not self.training:
+            return self.inference(batched_inputs)           # rcnn.py:353-354
         if branch == "caption_consistency":                     # rcnn.py:413-421
             both = self.preprocess_image_train(batched_inputs)
             cont, kd = self.v2l_contrastive(both, clipcap_model, KD_regularization)

@@ -17,7 +17,7 @@ from .._lib import to_device_async
 from ..registry import ROI_HEADS_REGISTRY
 from ..structures import Boxes, Instances, ShapeSpec, as_instances
 from .backbone import to_nhwc, to_nchw
-from .rpn import get_deltas, subsample_labels_batched
+from .rpn import apply_deltas, get_deltas, subsample_labels_batched
 
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))  # proposal_utils.py:183
 
@@ -56,6 +56,49 @@ class _Linear(nn.Module):
         return self._pw
 
 
+NMS_MAX_CANDIDATES = 12288      # cddmsl_nms handles 192 mask words of 64 boxes per image
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """layers/nms.py:19-39 -> torchvision.ops.batched_nms: per-category NMS through the coordinate-offset trick, on the HIP
+    sort + bit-mask NMS kernels.  Returns kept indices in descending-score order.  (More than 12 288 candidates per image
+    -- the kernel's limit -- would keep only the 12 288 highest-scoring ones; thresholded detections never get there.)"""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    boxes = boxes.float()
+    off = idxs.to(boxes) * (boxes.max() + 1.0)
+    keys, order = hip.sort_desc(scores.float().contiguous().view(1, n))
+    order = order[0].long()[:NMS_MAX_CANDIDATES]
+    m = order.numel()
+    sorted_boxes = (boxes + off[:, None])[order].view(1, m, 4).contiguous()
+    keep, nkeep = hip.nms(sorted_boxes, torch.ones((1, m), dtype=torch.uint8, device=boxes.device), float(iou_threshold), m)
+    return order[keep[0, : int(nkeep[0])].long()]
+
+
+def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
+    """fast_rcnn.py:130-209 (hard NMS): drop non-finite rows, clip, score threshold per (proposal, class), per-class NMS,
+    keep the top-k.  boxes [R, 4K], scores [R, K+1] -> (Instances, indices of the kept proposals)."""
+    valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+    if not bool(valid.all()):
+        boxes, scores = boxes[valid], scores[valid]
+    scores = scores[:, :-1]
+    k = boxes.shape[1] // 4
+    b = Boxes(boxes.reshape(-1, 4))
+    b.clip(image_shape)
+    boxes = b.tensor.view(-1, k, 4)
+    mask = scores > score_thresh
+    inds = mask.nonzero()                            # [R', 2] (proposal, class), row-major order as the reference
+    boxes = boxes[inds[:, 0], 0] if k == 1 else boxes[mask]
+    scores = scores[mask]
+    keep = batched_nms(boxes, scores, inds[:, 1], nms_thresh)
+    if topk_per_image >= 0:
+        keep = keep[:topk_per_image]
+    res = Instances(tuple(image_shape))
+    res.pred_boxes, res.scores, res.pred_classes = Boxes(boxes[keep]), scores[keep], inds[keep, 1]
+    return res, inds[keep, 0]
+
+
 class FastRCNNOutputLayers(nn.Module):
     """fast_rcnn.py:368-689, RegionCLIP text-embedding classifier branch."""
 
@@ -86,6 +129,13 @@ class FastRCNNOutputLayers(nn.Module):
         self.bg_cls_loss_weight = c.BG_CLS_LOSS_WEIGHT
         self.focal_scaled_loss = c.FOCAL_SCALED_LOSS
         self.loss_weight = {"loss_box_reg": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT}
+        # inference (fast_rcnn.py:398-407,432-437)
+        self.test_score_thresh = cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST
+        self.test_nms_thresh = cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST
+        self.test_topk_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        self.no_box_delta = bool(c.NO_BOX_DELTA)
+        self.multiply_rpn_score = bool(c.MULTIPLY_RPN_SCORE)
+        assert not cfg.MODEL.ROI_HEADS.get("SOFT_NMS_ENABLED", False), "soft-NMS is off the hot path (defaults.py:399)"
         self.compute_dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[cfg.MODEL.get("COMPUTE_DTYPE", "bf16")]
         self._wn = None
         self.storage = {}
@@ -134,6 +184,31 @@ class FastRCNNOutputLayers(nn.Module):
         loss_box = torch.abs(fg_pred - gt_d).sum() / max(gt_classes.numel(), 1.0)
         out = {"loss_cls": loss_cls, "loss_box_reg": loss_box}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
+
+    # ------------------------------------------------------------------ inference (fast_rcnn.py:47-209,691-811)
+    def predict_boxes(self, predictions, proposals):
+        """fast_rcnn.py:760-790 -> per image [Ri, 4K] class-specific boxes"""
+        if not len(proposals):
+            return []
+        _, deltas = predictions
+        pboxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        boxes = pboxes if self.no_box_delta else apply_deltas(deltas, pboxes, self.box_weights)
+        return boxes.split([len(p) for p in proposals])
+
+    def predict_probs(self, predictions, proposals):
+        """fast_rcnn.py:792-811: softmax over the K+1 logits"""
+        scores, _ = predictions
+        return F.softmax(scores.float(), dim=-1).split([len(p) for p in proposals], dim=0)
+
+    def inference(self, predictions, proposals):
+        """fast_rcnn.py:691-724 -> (list[Instances(pred_boxes, scores, pred_classes)], list[kept proposal indices])"""
+        boxes = self.predict_boxes(predictions, proposals)
+        scores = self.predict_probs(predictions, proposals)
+        if self.multiply_rpn_score and not self.training:   # geometric mean with the RPN objectness (fast_rcnn.py:708-710)
+            scores = [(s * p.objectness_logits[:, None]) ** 0.5 for s, p in zip(scores, proposals)]
+        out = [fast_rcnn_inference_single_image(b, s, p.image_size, self.test_score_thresh, self.test_nms_thresh,
+                                                self.test_topk_per_image) for b, s, p in zip(boxes, scores, proposals)]
+        return [o[0] for o in out], [o[1] for o in out]
 
     def _log_stats(self, scores, gt_classes):
         """_log_classification_stats fast_rcnn.py:100-127 (kept on device; no sync)."""
@@ -228,14 +303,24 @@ class CLIPRes5ROIHeads(nn.Module):
 
     def forward(self, images, features, proposals, targets=None, res5=None, attnpool=None):
         """clip_roi_heads.py:134-175 (training)."""
-        assert self.training and attnpool is not None, "inference is a 'next' row (SURVEY.md 8(f))"
-        assert targets
-        targets = [as_instances(t) for t in targets]
-        proposals = self.label_and_sample_proposals(proposals, targets)
+        assert attnpool is not None, "CLIPRes5ROIHeads is used with the backbone's attention pool (rcnn.py:606-612)"
+        if self.training:
+            assert targets
+            targets = [as_instances(t) for t in targets]
+            proposals = self.label_and_sample_proposals(proposals, targets)
         box_features = self._shared_roi_transform(to_nhwc(features[self.in_features[0]]), [p.proposal_boxes for p in proposals], res5)
         att = attnpool(to_nchw(box_features))
         predictions = self.box_predictor(att)
-        return [], self.box_predictor.losses(predictions, proposals)
+        if self.training:
+            return [], self.box_predictor.losses(predictions, proposals)
+        pred_instances, _ = self.box_predictor.inference(predictions, proposals)     # clip_roi_heads.py:171-174
+        return self.forward_with_given_boxes(features, pred_instances, res5), {}
+
+    def forward_with_given_boxes(self, features, instances, res5=None):
+        """clip_roi_heads.py:176-199 with MASK_ON False: nothing to add"""
+        assert not self.training
+        assert instances[0].has("pred_boxes") and instances[0].has("pred_classes")
+        return instances
 
 
 @ROI_HEADS_REGISTRY.register()
@@ -250,12 +335,17 @@ class Res5ROIHeads(CLIPRes5ROIHeads):
         self.res5 = make_stage(3, [2, 1, 1], out_channels // 2, r.get("WIDTH_PER_GROUP", 64) * 8, out_channels)   # _build_res5_block :440-463
 
     def forward(self, images, features, proposals, targets=None, res5=None, attnpool=None):
-        assert self.training and targets
-        targets = [as_instances(t) for t in targets]
-        proposals = self.label_and_sample_proposals(proposals, targets)
+        if self.training:
+            assert targets
+            targets = [as_instances(t) for t in targets]
+            proposals = self.label_and_sample_proposals(proposals, targets)
         x = self.pooler.forward_nhwc(to_nhwc(features[self.in_features[0]]), [p.proposal_boxes for p in proposals])
         feats = layers.mean_pool(self.res5.forward_nhwc(x))
-        return [], self.box_predictor.losses(self.box_predictor(feats), proposals)
+        predictions = self.box_predictor(feats)
+        if self.training:
+            return [], self.box_predictor.losses(predictions, proposals)
+        pred_instances, _ = self.box_predictor.inference(predictions, proposals)     # roi_heads.py:497-500
+        return self.forward_with_given_boxes(features, pred_instances), {}
 
 
 def build_roi_heads(cfg, input_shape):

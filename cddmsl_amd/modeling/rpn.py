@@ -34,6 +34,22 @@ def get_deltas(src, tgt, weights):
     return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), dim=1)
 
 
+def apply_deltas(deltas, boxes, weights, scale_clamp=SCALE_CLAMP):
+    """Box2BoxTransform.apply_deltas box_regression.py:77-115: deltas [N, 4k] (k class-specific transforms), boxes [N, 4]."""
+    deltas = deltas.float()
+    boxes = boxes.to(deltas.dtype)
+    w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+    wx, wy, ww, wh = weights
+    dx, dy = deltas[:, 0::4] / wx, deltas[:, 1::4] / wy
+    dw = torch.clamp(deltas[:, 2::4] / ww, max=scale_clamp)
+    dh = torch.clamp(deltas[:, 3::4] / wh, max=scale_clamp)
+    pcx, pcy = dx * w[:, None] + cx[:, None], dy * h[:, None] + cy[:, None]
+    pw, ph = torch.exp(dw) * w[:, None], torch.exp(dh) * h[:, None]
+    out = torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1)
+    return out.reshape(deltas.shape)
+
+
 def subsample_labels(labels, num_samples, positive_fraction, bg_label, gen):
     """sampling.py:9-54 with both permutations drawn from the replayable CPU generator ``gen``."""
     positive = torch.nonzero((labels != -1) & (labels != bg_label), as_tuple=True)[0]

@@ -34,6 +34,23 @@ class Boxes:
         b = self.tensor
         return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
 
+    def clip(self, box_size):
+        """boxes.py:192-206: clamp x to [0, width], y to [0, height] (box_size = (height, width)); in place."""
+        h, w = box_size
+        t = self.tensor
+        self.tensor = torch.stack((t[:, 0].clamp(min=0, max=w), t[:, 1].clamp(min=0, max=h),
+                                   t[:, 2].clamp(min=0, max=w), t[:, 3].clamp(min=0, max=h)), dim=-1)
+
+    def nonempty(self, threshold: float = 0.0):
+        """boxes.py:208-222"""
+        t = self.tensor
+        return ((t[:, 2] - t[:, 0]) > threshold) & ((t[:, 3] - t[:, 1]) > threshold)
+
+    def scale(self, scale_x, scale_y):
+        """boxes.py:280-285 (in place)"""
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
     @property
     def device(self):
         return self.tensor.device

@@ -41,6 +41,12 @@ class Cfg:
     rpn_smooth_l1_beta: float = 0.0
     rpn_pre_nms_topk: int = 12000
     rpn_post_nms_topk: int = 2000
+    rpn_pre_nms_topk_test: int = 6000     # config/defaults.py:344-355
+    rpn_post_nms_topk_test: int = 1000    # configs/Base-RCNN-C4.yaml:4-5
+    test_score_thresh: float = 0.05       # MODEL.ROI_HEADS.SCORE_THRESH_TEST
+    test_nms_thresh: float = 0.5          # MODEL.ROI_HEADS.NMS_THRESH_TEST
+    detections_per_image: int = 100       # TEST.DETECTIONS_PER_IMAGE
+    multiply_rpn_score: bool = False      # MODEL.CLIP.MULTIPLY_RPN_SCORE
     rpn_nms_thresh: float = 0.7
     rpn_min_box_size: float = 0.0
     num_classes: int = 20
@@ -267,7 +273,9 @@ def rpn_losses(cfg, anchors, logits, labels, deltas, matched):
 def find_top_rpn_proposals(cfg, proposals, logits, image_sizes, training=True, record=None):
     """proposal_utils.py:22-130, single feature level."""
     out = []
-    k = min(logits.shape[1], cfg.rpn_pre_nms_topk)
+    pre_topk = cfg.rpn_pre_nms_topk if training else cfg.rpn_pre_nms_topk_test
+    post_topk = cfg.rpn_post_nms_topk if training else cfg.rpn_post_nms_topk_test
+    k = min(logits.shape[1], pre_topk)
     srt = torch.sort(logits, descending=True, dim=1, stable=True)
     top_scores, top_idx = srt.values[:, :k], srt.indices[:, :k]
     for n, size in enumerate(image_sizes):
@@ -283,7 +291,7 @@ def find_top_rpn_proposals(cfg, proposals, logits, image_sizes, training=True, r
         if keep.sum().item() != len(boxes):
             boxes, scores = boxes[keep], scores[keep]
         keep = ops.batched_nms(boxes, scores, torch.zeros(len(boxes), dtype=torch.int64), cfg.rpn_nms_thresh)
-        keep = keep[: cfg.rpn_post_nms_topk]
+        keep = keep[:post_topk]
         if record is not None:
             record.setdefault("nms_keep", []).append(keep.clone())
         out.append((boxes[keep], scores[keep]))
@@ -421,6 +429,61 @@ def roi_heads_forward(sd, cfg, res4, proposals, gt_boxes_list, gt_classes_list, 
         record["stats"] = classification_stats(scores.detach(), gt_classes)
     return {"loss_cls": focal_loss(cfg, scores, gt_classes),
             "loss_box_reg": box_reg_loss(cfg, pboxes, gboxes, deltas, gt_classes)}
+
+
+# ------------------------------------------------------------------------------------------------
+# inference  (fast_rcnn.py:47-209,691-811; clip_roi_heads.py:171-174; meta_arch/rcnn.py:690-784; postprocessing.py:9-75)
+# ------------------------------------------------------------------------------------------------
+def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
+    """fast_rcnn.py:130-209 with hard NMS: boxes [R, 4K], scores [R, K+1] -> (boxes [D,4], scores [D], classes [D], proposal idx [D])"""
+    valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+    if not valid.all():
+        boxes, scores = boxes[valid], scores[valid]
+    scores = scores[:, :-1]
+    k = boxes.shape[1] // 4
+    boxes = ops.clip_boxes(boxes.reshape(-1, 4), image_shape).view(-1, k, 4)
+    mask = scores > score_thresh
+    inds = mask.nonzero()
+    boxes = boxes[inds[:, 0], 0] if k == 1 else boxes[mask]
+    scores = scores[mask]
+    keep = ops.batched_nms(boxes, scores, inds[:, 1], nms_thresh)
+    if topk_per_image >= 0:
+        keep = keep[:topk_per_image]
+    return boxes[keep], scores[keep], inds[keep, 1], inds[keep, 0]
+
+
+def detector_postprocess(boxes, scores, classes, image_size, out_h, out_w):
+    """postprocessing.py:9-75 (boxes): rescale to the output resolution, clip, drop empty boxes"""
+    sx, sy = out_w / image_size[1], out_h / image_size[0]
+    b = boxes.clone()
+    b[:, 0::2] *= sx
+    b[:, 1::2] *= sy
+    b = ops.clip_boxes(b, (out_h, out_w))
+    keep = ops.nonempty(b)
+    return b[keep], scores[keep], classes[keep]
+
+
+@torch.no_grad()
+def inference(sd, cfg, batched_inputs):
+    """GeneralizedRCNN.inference rcnn.py:690-756 -> per image dict(boxes, scores, classes) at the sample's height / width"""
+    images, sizes = preprocess_image(cfg, batched_inputs, "image")
+    res4 = backbone(sd, cfg, images, want_res5=False)["res4"]
+    props, _ = rpn_forward(sd, cfg, res4, sizes, None, None, training=False)
+    x = roi_pool(cfg, res4, [b for b, _ in props])
+    feats = attnpool(sd, cfg, layer4(sd, cfg, x))
+    scores, deltas = box_predictor(sd, cfg, feats)
+    pboxes = torch.cat([b for b, _ in props])
+    pred = ops.apply_deltas(deltas, pboxes, cfg.roi_bbox_weights)
+    probs = F.softmax(scores, dim=-1)
+    counts = [len(b) for b, _ in props]
+    out = []
+    for inp, size, pb, pr, (_, logit) in zip(batched_inputs, sizes, pred.split(counts), probs.split(counts), props):
+        if cfg.multiply_rpn_score:
+            pr = (pr * logit[:, None]) ** 0.5
+        b, s, c, _ = fast_rcnn_inference_single_image(pb, pr, size, cfg.test_score_thresh, cfg.test_nms_thresh, cfg.detections_per_image)
+        b, s, c = detector_postprocess(b, s, c, size, inp.get("height", size[0]), inp.get("width", size[1]))
+        out.append({"boxes": b, "scores": s, "classes": c})
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -154,3 +154,49 @@ def test_stock_r50_c4_config1_matches_oracle():
         worst = max(worst, err)
         assert err < 5e-3, (k, err)
     print("stock R50-C4 losses", got, "worst grad rel err", worst)
+
+
+def test_inference_and_voc_map_match_oracle(tmp_path):
+    """eval-mode forward (RPN test top-k, RoI head without sampling, softmax scores, per-class NMS,
+    top-k, rescale to the sample's height/width) on the HIP path (f32) vs the CPU oracle, then VOC07 AP of both against
+    the same synthetic ground truth: detections agree and mAP is within 1e-3 relative (BASELINE.json north_star)."""
+    from cddmsl_amd import synthetic
+    from cddmsl_amd import evaluation as ev
+    from cddmsl_amd.structures import Boxes, Instances
+    from oracle import model as om
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cfg = _cfg("f32")
+    cfg.merge_from_list(["MODEL.RPN.PRE_NMS_TOPK_TEST", 400, "MODEL.RPN.POST_NMS_TOPK_TEST", 60, "TEST.DETECTIONS_PER_IMAGE", 30])
+    model, _, sd, _ = _build(cfg, seed=3)
+    model.eval()
+    batch = synthetic.make_batch(3, 160, 224, num_gt=3)
+    for i, x in enumerate(batch):                      # dataset-dict fields the postprocess / evaluator read
+        x["height"], x["width"], x["image_id"] = 320, 448, f"im{i}"
+    got = model(batch)
+    ocfg = om.Cfg(rpn_pre_nms_topk_test=400, rpn_post_nms_topk_test=60, detections_per_image=30)
+    want = om.inference(sd, ocfg, batch)
+    assert sum(len(w["scores"]) for w in want) > 10, "degenerate case: nothing detected"
+    for g, w in zip(got, want):
+        inst = g["instances"]
+        assert inst.image_size == (320, 448)
+        assert len(inst) == len(w["scores"]), (len(inst), len(w["scores"]))
+        assert torch.equal(inst.pred_classes.cpu(), w["classes"])
+        assert (inst.scores.cpu() - w["scores"]).abs().max() <= 1e-3 * max(float(w["scores"].abs().max()), 1e-6)
+        assert (inst.pred_boxes.tensor.cpu() - w["boxes"]).abs().max() <= 1e-2        # pixels at 448x320
+    # mAP parity on a synthetic annotation set: the samples' GT boxes (scaled to the output resolution) as "aeroplane".. classes
+    names = list(ev.VOC_CLASS_NAMES)
+    os.makedirs(tmp_path / "Annotations"), os.makedirs(tmp_path / "ImageSets" / "Main")
+    for x in batch:
+        objs = []
+        for b, c in zip(x["instances"]["gt_boxes"].tolist(), x["instances"]["gt_classes"].tolist()):
+            objs.append("<object><name>%s</name><difficult>0</difficult><bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+                        % (names[c], int(2 * b[0]) + 1, int(2 * b[1]) + 1, int(2 * b[2]), int(2 * b[3])))
+        (tmp_path / "Annotations" / (x["image_id"] + ".xml")).write_text("<annotation>" + "".join(objs) + "</annotation>")
+    (tmp_path / "ImageSets" / "Main" / "test.txt").write_text("\n".join(x["image_id"] for x in batch) + "\n")
+    res = []
+    for outs in (got, [{"instances": Instances((320, 448), pred_boxes=Boxes(w["boxes"]), scores=w["scores"], pred_classes=w["classes"])} for w in want]):
+        e = ev.PascalVOCDetectionEvaluator(str(tmp_path), "test", 2007)
+        e.process(batch, outs)
+        res.append(e.evaluate()["bbox"])
+    for k in ("AP", "AP50", "AP75"):
+        assert abs(res[0][k] - res[1][k]) <= 1e-3 * max(abs(res[1][k]), 1e-9), (k, res[0][k], res[1][k])

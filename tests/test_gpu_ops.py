@@ -293,3 +293,19 @@ def test_small_attention_fwd_bwd(n, t):
     for got, want, name in ((o, ref, "o"), (qg.grad, qr.grad, "dq"), (kvg.grad, kvr.grad, "dkv")):
         err = (got.float().cpu() - want.detach()).abs().max() / want.detach().abs().max()
         assert err < 2e-2, (name, float(err))
+
+
+def test_fast_rcnn_inference_single_image_matches_reference():
+    """Detection post-processing on the HIP sort / NMS kernels vs the reference's own fast_rcnn_inference_single_image and
+    detector_postprocess (tests/golden/ref_inference.npz): same kept (proposal, class) pairs in the same order."""
+    import numpy as np
+    from cddmsl_amd.modeling.postprocessing import detector_postprocess
+    from cddmsl_amd.modeling.roi_heads import fast_rcnn_inference_single_image
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_inference.npz"))
+    inst, kept = fast_rcnn_inference_single_image(torch.from_numpy(fx["boxes"]).cuda(), torch.from_numpy(fx["scores"]).cuda(), (200, 300), 0.05, 0.5, 20)
+    assert torch.equal(inst.pred_classes.cpu(), torch.from_numpy(fx["det_classes"]))
+    assert torch.equal(kept.cpu(), torch.from_numpy(fx["det_kept"]))
+    assert torch.equal(inst.pred_boxes.tensor.cpu(), torch.from_numpy(fx["det_boxes"])) and torch.equal(inst.scores.cpu(), torch.from_numpy(fx["det_scores"]))
+    post = detector_postprocess(inst, 333, 480)
+    assert post.image_size == (333, 480) and torch.equal(post.pred_classes.cpu(), torch.from_numpy(fx["post_classes"]))
+    assert torch.allclose(post.pred_boxes.tensor.cpu(), torch.from_numpy(fx["post_boxes"]), rtol=0, atol=1e-4)

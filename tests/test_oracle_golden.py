@@ -180,3 +180,69 @@ def test_ref_roialign():
     assert np.allclose(out.detach().numpy(), g["out"], rtol=1e-5, atol=1e-6)
     (out * T(g["w"])).sum().backward()
     assert np.allclose(x.grad.numpy(), g["gx"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ inference / evaluation rows
+def _write_voc(root, data, split="test"):
+    os.makedirs(os.path.join(root, "Annotations"), exist_ok=True)
+    os.makedirs(os.path.join(root, "ImageSets", "Main"), exist_ok=True)
+    for name, objs in data.items():
+        xml = ["<annotation>"]
+        for o in objs:
+            xml.append("<object><name>%s</name><pose>Unspecified</pose><truncated>0</truncated><difficult>%d</difficult>"
+                       "<bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+                       % (o["name"], o["difficult"], *o["bbox"]))
+        xml.append("</annotation>")
+        with open(os.path.join(root, "Annotations", name + ".xml"), "w") as f:
+            f.write("".join(xml))
+    with open(os.path.join(root, "ImageSets", "Main", split + ".txt"), "w") as f:
+        f.write("\n".join(data.keys()) + "\n")
+
+
+def test_voc_ap_matches_reference_voc_eval(tmp_path):
+    """cddmsl_amd.evaluation (the product's CPU evaluator) vs AP values produced by the reference's own voc_eval
+    (tests/golden/make_golden_eval.py): VOC07 11-point and area AP, IoU .50 / .75, incl. difficult boxes, duplicates, score ties."""
+    import json
+    import numpy as np
+    from cddmsl_amd import evaluation as ev
+    fx = json.load(open(os.path.join(G, "ref_voc_eval.json")))
+    _write_voc(str(tmp_path), fx["data"])
+    names = list(fx["data"].keys())
+    recs = {n: ev.read_voc_objects(os.path.join(str(tmp_path), "Annotations", n + ".xml")) for n in names}
+    for c in fx["classes"]:
+        gt = {n: (np.array([o["bbox"] for o in recs[n] if o["name"] == c], dtype=float).reshape(-1, 4),
+                  np.array([o["difficult"] for o in recs[n] if o["name"] == c], dtype=bool)) for n in names}
+        lines = [l.split(" ") for l in fx["dets"][c]]
+        ids = [l[0] for l in lines]
+        conf = np.array([float(l[1]) for l in lines])
+        bbs = np.array([[float(z) for z in l[2:]] for l in lines]).reshape(-1, 4)
+        for thr in (0.5, 0.75):
+            for m07 in (True, False):
+                got = ev.class_ap(ids, conf, bbs, gt, thr, m07)
+                assert abs(got - fx["ap"][f"{c}|{thr}|{int(m07)}"]) < 1e-12, (c, thr, m07)
+    # the evaluator object end to end (process -> evaluate): AP50 of the 2007 metric = mean over classes of the values above
+    from cddmsl_amd.structures import Boxes, Instances
+    e = ev.PascalVOCDetectionEvaluator(str(tmp_path), "test", 2007, class_names=fx["classes"])
+    for n in names:
+        rows = [(ci, l.split(" ")) for ci, c in enumerate(fx["classes"]) for l in fx["dets"][c] if l.split(" ")[0] == n]
+        inst = Instances((1, 1))
+        # undo the writer's +1 on xmin / ymin so that process() reproduces the stored line
+        inst.pred_boxes = Boxes(torch.tensor([[float(l[2]) - 1, float(l[3]) - 1, float(l[4]), float(l[5])] for _, l in rows], dtype=torch.float64).reshape(-1, 4).float())
+        inst.scores = torch.tensor([float(l[1]) for _, l in rows])
+        inst.pred_classes = torch.tensor([ci for ci, _ in rows], dtype=torch.int64)
+        e.process([{"image_id": n}], [{"instances": inst}])
+    out = e.evaluate()["bbox"]
+    want50 = 100 * np.mean([fx["ap"][f"{c}|0.5|1"] for c in fx["classes"]])
+    assert abs(out["AP50"] - want50) < 1e-6 * max(want50, 1.0), (out["AP50"], want50)
+
+
+def test_oracle_inference_matches_reference():
+    """oracle fast_rcnn_inference_single_image / detector_postprocess vs the reference's own functions (ref_inference.npz)."""
+    from oracle import model as om
+    fx = np.load(os.path.join(G, "ref_inference.npz"))
+    b, s, c, kept = om.fast_rcnn_inference_single_image(torch.from_numpy(fx["boxes"]), torch.from_numpy(fx["scores"]), (200, 300), 0.05, 0.5, 20)
+    assert torch.equal(c, torch.from_numpy(fx["det_classes"])) and torch.equal(kept, torch.from_numpy(fx["det_kept"]))
+    assert torch.equal(b, torch.from_numpy(fx["det_boxes"])) and torch.equal(s, torch.from_numpy(fx["det_scores"]))
+    pb, ps, pc = om.detector_postprocess(b, s, c, (200, 300), 333, 480)
+    assert torch.allclose(pb, torch.from_numpy(fx["post_boxes"]), rtol=0, atol=1e-4) and torch.equal(pc, torch.from_numpy(fx["post_classes"]))
+    assert torch.equal(ps, torch.from_numpy(fx["post_scores"]))
