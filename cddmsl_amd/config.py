@@ -112,7 +112,8 @@ def get_cfg():
                      "NO_BOX_DELTA": False, "BG_CLS_LOSS_WEIGHT": None, "ONLY_SAMPLE_FG_PROPOSALS": False,
                      "CLSS_TEMP": 0.01, "FOCAL_SCALED_LOSS": None, "MULTIPLY_RPN_SCORE": False},
         },
-        "INPUT": {"MIN_SIZE_TRAIN": (800,), "MAX_SIZE_TRAIN": 1333, "MIN_SIZE_TEST": 800, "MAX_SIZE_TEST": 1333, "FORMAT": "BGR"},
+        "INPUT": {"MIN_SIZE_TRAIN": (800,), "MAX_SIZE_TRAIN": 1333, "MIN_SIZE_TEST": 800, "MAX_SIZE_TEST": 1333, "FORMAT": "BGR",
+                  "MIN_SIZE_TRAIN_SAMPLING": "choice", "RANDOM_FLIP": "horizontal"},
         "DATASETS": {"TRAIN": (), "TEST": ()},
         "DATALOADER": {"NUM_WORKERS": 4, "ASPECT_RATIO_GROUPING": True},
         "SOLVER": {"IMS_PER_BATCH": 16, "BASE_LR": 0.001, "MOMENTUM": 0.9, "NESTEROV": False, "WEIGHT_DECAY": 0.0001,

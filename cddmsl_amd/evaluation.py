@@ -159,3 +159,16 @@ def inference_on_dataset(model, data_loader, evaluator):
         evaluator.process(inputs, model(inputs))
     model.train(was_training)
     return evaluator.evaluate()
+
+
+def run_eval_only(model, cfg, args, rank=0, world=1):
+    """tools/train_caption_consistency.py:143-152 (``--eval-only``): VOC-style test set under ``args.voc_root`` -> AP dict
+    printed by rank 0.  Returns the process exit code."""
+    from .data import build_detection_test_loader, load_voc_instances
+    dicts = load_voc_instances(args.voc_root, args.voc_split, VOC_CLASS_NAMES[: cfg.MODEL.ROI_HEADS.NUM_CLASSES])
+    loader = build_detection_test_loader(cfg, dicts, batch_size=1, rank=rank, world=world, device=cfg.MODEL.DEVICE)
+    ev = PascalVOCDetectionEvaluator(args.voc_root, args.voc_split, args.voc_year, VOC_CLASS_NAMES[: cfg.MODEL.ROI_HEADS.NUM_CLASSES])
+    res = inference_on_dataset(model, loader, ev)
+    if rank == 0:
+        print({k: round(v, 4) for k, v in res["bbox"].items()})
+    return 0

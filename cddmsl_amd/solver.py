@@ -39,6 +39,18 @@ class ClippedSGD:
             if p.grad is not None:
                 p.grad.zero_()
 
+    def state_dict(self):
+        """momentum buffers in parameter order (torch.optim.SGD's 'state' keyed by parameter index) + step counters"""
+        moms = None if self.moms is None else [self.moms[id(p)].detach().cpu() for p in self.params]
+        return {"momentum_buffers": moms, "steps_done": self.steps_done, "iteration": self.iteration}
+
+    def load_state_dict(self, sd):
+        self.steps_done, self.iteration = int(sd["steps_done"]), int(sd["iteration"])
+        if sd["momentum_buffers"] is not None:
+            assert len(sd["momentum_buffers"]) == len(self.params)
+            self.moms = {id(p): m.to(p.device).clone(memory_format=torch.preserve_format) for p, m in zip(self.params, sd["momentum_buffers"])}
+            self.norm_ws = torch.zeros(len(self.params), device=self.params[0].device, dtype=torch.float32)
+
     def step(self):
         touched = layers.take_touched()     # torch.optim.SGD skips parameters whose grad is None (e.g. the projector in stock configs)
         ps = [p for p in self.params if p.grad is not None and id(p) in touched]

@@ -1,0 +1,143 @@
+"""Host-side rows next to the hot path (SURVEY.md 8(f)2,4): paired VOC data pipeline and checkpoint compatibility.
+CPU only.  The reference's transform classes cannot be imported here (they derive from fvcore, not installed), so the
+resize numerics are checked against the PIL call both sides make and the geometry against hand-computed values
+(parity unpinned by reference fixtures; see cddmsl_amd/data.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cddmsl_amd import data
+from cddmsl_amd.config import get_cfg
+
+CLASSES = data.VOC_CLASS_NAMES
+
+
+def _make_voc(root, n=7, year="VOC2007", twin="clipart"):
+    from PIL import Image
+    g = np.random.RandomState(0)
+    base = os.path.join(root, "VOC", year)
+    tw = os.path.join(root, "VOC", "..", twin, year)      # <dirname>/../<dt_data>/<VOC2007>
+    tw = os.path.normpath(os.path.join(base, "..", twin, year))
+    for d in (os.path.join(base, "Annotations"), os.path.join(base, "ImageSets", "Main"), os.path.join(base, "JPEGImages"), os.path.join(tw, "JPEGImages")):
+        os.makedirs(d, exist_ok=True)
+    ids = []
+    for i in range(n):
+        w, h = (120, 90) if i % 3 else (80, 130)
+        fid = f"{i:06d}"
+        ids.append(fid)
+        img = g.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        Image.fromarray(img).save(os.path.join(base, "JPEGImages", fid + ".jpg"), quality=95)
+        Image.fromarray(255 - img).save(os.path.join(tw, "JPEGImages", fid + ".jpg"), quality=95)
+        objs = "".join("<object><name>%s</name><difficult>%d</difficult><bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+                       % (CLASSES[(i + k) % 20], k % 2, 5 + 7 * k, 3 + 5 * k, 40 + 9 * k, 50 + 4 * k) for k in range(1 + i % 3))
+        open(os.path.join(base, "Annotations", fid + ".xml"), "w").write(
+            f"<annotation><size><width>{w}</width><height>{h}</height></size>{objs}</annotation>")
+    for split in ("trainval", "test"):
+        open(os.path.join(base, "ImageSets", "Main", split + ".txt"), "w").write("\n".join(ids) + "\n")
+    return base
+
+
+def test_voc_dicts_and_mapper(tmp_path):
+    base = _make_voc(str(tmp_path))
+    dicts = data.load_voc_instances(base, "trainval", dt_data="clipart")
+    assert len(dicts) == 7 and dicts[1]["annotations"][0]["bbox"] == [4.0, 2.0, 40.0, 50.0]          # xmin-1, ymin-1
+    assert dicts[0]["data_dt_file_name"].endswith(os.path.join("clipart", "VOC2007", "JPEGImages", "000000.jpg"))
+    assert "data_dt_file_name" not in data.load_voc_instances(base, "test", dt_data="clipart")[0]       # twins only for training splits
+    cfg = get_cfg()
+    cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (64, 96), "INPUT.MAX_SIZE_TRAIN", 128, "INPUT.FORMAT", "RGB"])
+
+    class FixedRng:                                  # scripted draws: short edge 96, flip
+        def choice(self, a):
+            return a[1]
+
+        def uniform(self):
+            return 0.1
+
+    m = data.DatasetMapper(cfg, True, FixedRng())
+    out = m(dicts[1])                                # 120 x 90 (w x h): short edge 96 -> 128 x 96, capped at max 128 exactly
+    assert tuple(out["image"].shape) == (3, 96, 128) and out["image"].dtype == torch.uint8
+    assert tuple(out["image_trgt"].shape) == (3, 96, 128)
+    from PIL import Image
+    src = data.read_image(dicts[1]["file_name"], "RGB")
+    want = np.asarray(Image.fromarray(src).resize((128, 96), Image.BILINEAR))[:, ::-1]
+    assert np.array_equal(out["image"].numpy().transpose(1, 2, 0), want)
+    twin = data.read_image(dicts[1]["data_dt_file_name"], "RGB")
+    assert np.array_equal(out["image_trgt"].numpy().transpose(1, 2, 0), np.asarray(Image.fromarray(twin).resize((128, 96), Image.BILINEAR))[:, ::-1])
+    sx, sy = 128 / 120, 96 / 90
+    b = out["instances"].gt_boxes.tensor[0].tolist()           # [4, 2, 40, 50] scaled, then flipped in x
+    assert np.allclose(b, [128 - 40 * sx, 2 * sy, 128 - 4 * sx, 50 * sy], atol=1e-4)
+    assert out["instances"].image_size == (96, 128) and out["instances"].gt_classes.dtype == torch.int64
+    # test-time mapper: MIN_SIZE_TEST, no flip, annotations dropped
+    mt = data.DatasetMapper(cfg, False)
+    o = mt(dicts[0])                                 # 80 x 130 (w x h): short edge 80 -> 800, long edge 1300 <= MAX_SIZE_TEST
+    assert "instances" not in o and tuple(o["image"].shape) == (3, 1300, 800) and o["height"] == 130
+
+
+def test_sampler_grouping_and_loader(tmp_path):
+    base = _make_voc(str(tmp_path), n=9)
+    dicts = data.load_voc_instances(base, "trainval", dt_data="clipart")
+    # two ranks see disjoint, interleaved slices of ONE permutation stream
+    a = data.TrainingSampler(9, True, 5, 0, 2)
+    b = data.TrainingSampler(9, True, 5, 1, 2)
+    one = data.TrainingSampler(9, True, 5, 0, 1)
+    ia, ib, io = iter(a), iter(b), iter(one)
+    merged = [next(io) for _ in range(18)]
+    assert [next(ia) for _ in range(9)] == merged[0::2] and [next(ib) for _ in range(9)] == merged[1::2]
+    assert sorted(merged[:9]) == list(range(9))
+    cfg = get_cfg()
+    cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (64,), "INPUT.MAX_SIZE_TRAIN", 128, "INPUT.FORMAT", "RGB", "SEED", 3])
+    loader = data.build_detection_train_loader(cfg, dicts, per_rank_batch=2, device="cpu", num_workers=0)
+    for _ in range(4):
+        batch = next(loader)
+        assert len(batch) == 2
+        land = [x["image"].shape[2] > x["image"].shape[1] for x in batch]
+        assert land[0] == land[1]                    # aspect-ratio grouping
+        for x in batch:
+            assert x["image"].shape == x["image_trgt"].shape and len(x["instances"]) >= 1
+    # worker processes deliver the same kind of batches
+    loader = data.build_detection_train_loader(cfg, dicts, per_rank_batch=2, device="cpu", num_workers=2)
+    assert len(next(loader)) == 2
+    test = list(data.build_detection_test_loader(cfg, data.load_voc_instances(base, "test"), batch_size=2, rank=1, world=2, device="cpu"))
+    assert [x["image_id"] for bt in test for x in bt] == ["000005", "000006", "000007", "000008"]   # InferenceSampler shard of rank 1
+
+
+def test_checkpoint_roundtrip_and_side_loads(tmp_path):
+    from cddmsl_amd import synthetic
+    from cddmsl_amd.checkpoint import DetectionCheckpointer, offline_backbone_state
+    from cddmsl_amd.modeling import build_model
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "VOC-Experiments", "faster_rcnn_CLIP_R_50_C4.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    model = build_model(cfg)
+    sd = synthetic.make_state_dict(0)
+    # a reference-format file: {"model": {...}} with the reference's parameter names, one wrong-shaped tensor, one stranger
+    bad = dict(sd)
+    bad["roi_heads.box_predictor.bbox_pred.bias"] = torch.zeros(7)
+    bad["lang_encoder.token_embedding.weight"] = torch.zeros(3, 3)
+    path = str(tmp_path / "regionclip_like.pth")
+    torch.save({"model": bad, "iteration": 41}, path)
+    ck = DetectionCheckpointer(model, str(tmp_path / "out"))
+    inc = ck.load(path)
+    assert inc.incorrect_shapes == [("roi_heads.box_predictor.bbox_pred.bias", (7,), (80,))]
+    assert inc.unexpected_keys == ["lang_encoder.token_embedding.weight"]
+    assert all(k.startswith(("offline_backbone.", "projector.")) or "bbox_pred.bias" in k or "cell_anchors" in k for k in inc.missing_keys), inc.missing_keys
+    got = model.state_dict()
+    for k in ("backbone.layer3.2.conv2.weight", "backbone.attnpool.k_proj.weight", "proposal_generator.rpn_head.conv.weight"):
+        assert torch.equal(got[k], sd[k])
+    # PRE_TRAINED_RCLIP_PATH -> offline_backbone (train_loop.py:150-161)
+    assert set(offline_backbone_state(sd)) == {k[9:] for k in sd if k.startswith("backbone.")}
+    ck.load_offline_backbone(path)
+    assert torch.equal(model.offline_backbone.state_dict()["layer2.1.conv3.weight"], sd["backbone.layer2.1.conv3.weight"])
+    # save -> resume
+    p2 = ck.save("model_0000041", iteration=41)
+    model2 = build_model(cfg)
+
+    class T:
+        iter = 0
+    t = T()
+    inc2 = DetectionCheckpointer(model2, str(tmp_path / "out"), trainer=t).resume_or_load("", resume=True)
+    assert t.iter == 42 and not inc2.unexpected_keys and not inc2.incorrect_shapes and os.path.basename(p2) == "model_0000041.pth"
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, model2.state_dict()[k]), k

@@ -5,8 +5,10 @@
         MODEL.CLIP.TEXT_EMB_PATH voc_20_cls_emb.pth SOLVER.IMS_PER_BATCH 128
 
 One process per GPU (engine/launch.py:67-80): with --num-gpus > 1 this script re-launches itself under
-``torch.distributed.run`` (RCCL over xGMI).  Datasets are not available offline, so the loader is the seeded synthetic
-paired-batch generator (``--synthetic`` is implied); real VOC+domain-twin loading is a "next" row.
+``torch.distributed.run`` (RCCL over xGMI).  Datasets are not available offline, so by default the loader is the seeded synthetic
+paired-batch generator; ``--voc-root <VOCdevkit/VOC2007> --dt-data <twin dir>`` switches to the real paired VOC pipeline
+(cddmsl_amd/data.py), ``--eval-only --voc-root ...`` runs inference + Pascal VOC AP (cddmsl_amd/evaluation.py), and
+``MODEL.WEIGHTS`` / ``--resume`` / ``MODEL.PRE_TRAINED_RCLIP_PATH`` go through cddmsl_amd/checkpoint.py.
 """
 import argparse
 import os
@@ -29,6 +31,11 @@ def default_argument_parser():
     p.add_argument("--max-iter", type=int, default=None, help="stop after this many iterations (default: SOLVER.MAX_ITER)")
     p.add_argument("--height", type=int, default=800)
     p.add_argument("--width", type=int, default=1333)
+    p.add_argument("--voc-root", default="", help="VOC devkit year directory (Annotations/, ImageSets/Main/, JPEGImages/) for --eval-only")
+    p.add_argument("--voc-split", default="test")
+    p.add_argument("--dt-data", default="", help="directory name of the domain-translated twins next to the VOC root (e.g. clipart); "
+                                                 "with --voc-root, train on the real paired loader instead of synthetic batches")
+    p.add_argument("--voc-year", type=int, default=2007)
     p.add_argument("opts", default=None, nargs=argparse.REMAINDER)
     return p
 
@@ -47,21 +54,41 @@ def main(args):
     from cddmsl_amd import engine, synthetic
     rank, world = engine.init_distributed()
     cfg = setup(args)
-    assert not args.eval_only, "evaluation is a 'next' row (SURVEY.md 8(f))"
     cfg.MODEL.DEVICE = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
     torch.cuda.set_device(cfg.MODEL.DEVICE)
     per_rank = max(cfg.SOLVER.IMS_PER_BATCH // world, 1)       # data/build.py:287
     tr = engine.build_trainer(cfg, per_rank, args.height, args.width, seed=cfg.SEED)
-    if not cfg.MODEL.WEIGHTS:
+    from cddmsl_amd.checkpoint import DetectionCheckpointer
+    ckpt = DetectionCheckpointer(tr.model, cfg.OUTPUT_DIR, optimizer=tr.optimizer, trainer=tr)
+    if not cfg.MODEL.WEIGHTS:       # no checkpoints offline: seeded synthetic weights
         tr.model.load_state_dict(synthetic.make_state_dict(0, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES), strict=False)
         tr.clipcap_model.load_state_dict(synthetic.make_mapper_state_dict(1))
-    else:
-        tr.model.load_state_dict(torch.load(cfg.MODEL.WEIGHTS, map_location="cpu", weights_only=True)["model"], strict=False)
+    else:                           # defaults.py:396-413 resume_or_load
+        inc = ckpt.resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
+        if rank == 0:
+            print(f"checkpoint: {len(inc.missing_keys)} missing, {len(inc.unexpected_keys)} unexpected, {len(inc.incorrect_shapes)} shape-skipped")
+    if cfg.MODEL.get("PRE_TRAINED_RCLIP_PATH", ""):
+        ckpt.load_offline_backbone(cfg.MODEL.PRE_TRAINED_RCLIP_PATH)          # train_loop.py:150-161
+    if args.eval_only:              # train_caption_consistency.py:143-152: model.eval(); inference over the test sets
+        from cddmsl_amd import evaluation
+        assert args.voc_root, "--eval-only needs --voc-root (a VOC devkit year directory) : datasets are not shipped"
+        raise SystemExit(evaluation.run_eval_only(tr.model, cfg, args, rank))
+    if args.voc_root and args.dt_data:      # real paired data; default: seeded synthetic batches
+        from cddmsl_amd import data
+        from cddmsl_amd.evaluation import VOC_CLASS_NAMES
+        dicts = data.load_voc_instances(args.voc_root, "trainval", VOC_CLASS_NAMES[: cfg.MODEL.ROI_HEADS.NUM_CLASSES], dt_data=args.dt_data)
+        tr.data_loader = data.build_detection_train_loader(cfg, dicts, per_rank, rank, world, cfg.MODEL.DEVICE)
+        tr._data_loader_iter = iter(tr.data_loader)
     max_iter = args.max_iter or cfg.SOLVER.MAX_ITER
-    for it in range(max_iter):
+    period = cfg.SOLVER.get("CHECKPOINT_PERIOD", 0)
+    for it in range(tr.iter, max_iter):
         tr.run_step()
         if rank == 0 and tr.metrics_period and it % tr.metrics_period == 0:
             print(f"iter {it}  " + "  ".join(f"{k}: {v:.4f}" for k, v in sorted(tr.storage.items())), flush=True)
+        if rank == 0 and period and (it + 1) % period == 0:                   # hooks.PeriodicCheckpointer
+            ckpt.save(f"model_{it:07d}", iteration=it)
+    if rank == 0 and period:
+        ckpt.save("model_final", iteration=max_iter - 1)
 
 
 if __name__ == "__main__":
