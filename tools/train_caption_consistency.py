@@ -67,8 +67,11 @@ def main(args):
         inc = ckpt.resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume)
         if rank == 0:
             print(f"checkpoint: {len(inc.missing_keys)} missing, {len(inc.unexpected_keys)} unexpected, {len(inc.incorrect_shapes)} shape-skipped")
-    if cfg.MODEL.get("PRE_TRAINED_RCLIP_PATH", ""):
-        ckpt.load_offline_backbone(cfg.MODEL.PRE_TRAINED_RCLIP_PATH)          # train_loop.py:150-161
+    rclip = cfg.MODEL.get("PRE_TRAINED_RCLIP_PATH", "")
+    if rclip and os.path.exists(rclip):
+        ckpt.load_offline_backbone(rclip)                                     # train_loop.py:150-161
+    elif rclip and rank == 0:
+        print(f"MODEL.PRE_TRAINED_RCLIP_PATH {rclip} not found: the offline (teacher) backbone keeps its loaded / synthetic weights")
     if args.eval_only:              # train_caption_consistency.py:143-152: model.eval(); inference over the test sets
         from cddmsl_amd import evaluation
         assert args.voc_root, "--eval-only needs --voc-root (a VOC devkit year directory) : datasets are not shipped"
