@@ -1780,8 +1780,12 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   int cols = 256 / es;
   long tiles = (long)((Cout + cols - 1) / cols) * ((a.K + cols - 1) / cols);
   int total_mt = (a.M + WM - 1) / WM;
-  // enough splits to fill 256 CUs a few times over, but at least 8 m-tiles of work per block
-  long want = (2048 + tiles - 1) / tiles;
+  // Split count: one round of blocks (2 per CU) for 1x1 layers, two for filters with taps, and at least 8 m-tiles per block.
+  // Every block ends with 16 Ki f32 atomics; with 2048+ blocks the atomic traffic at L2, not the reduction, set the
+  // time of the short backbone layers (measured: 150 -> 67 us at M = 66 400, N = 1024, K = 256).
+  const char* eb = getenv("CDDMSL_WGRAD_BLOCKS");                  // tuning knob (A/B runs): target number of blocks
+  const long target = eb ? atol(eb) : ((KH == 1 && KW == 1) ? 512 : 1024);
+  long want = (target + tiles - 1) / tiles;
   long maxs = (total_mt + 7) / 8;
   long splits = want < 1 ? 1 : (want > maxs ? maxs : want);
   if (splits < 1) splits = 1;
