@@ -1795,11 +1795,24 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   const bool same = !pool && stride == 1 && a.Ho == Hi && a.Wo == Wi;   // LDS-DMA kernel: output pixel == input pixel
   if (same && dtype == 0 && wgrad256_ok(a, 1)) {
-    // 256x256 ping-pong kernel: one block per CU, so fewer and longer splits
+    // 256x256 ping-pong kernel: ONE block per CU, so the grid should be a whole number of 256-block rounds: take the split
+    // count whose grid fills its last round best (fewest rounds on ties: every block ends with 64 Ki atomics), with at
+    // least 16 reduction tiles per block.  Measured on N = 2048, K = 512: 256 blocks 683 us vs 640 blocks 894 us.
     long tiles2 = (long)(Cout / 256) * (a.K / 256);
-    long want2 = (640 + tiles2 - 1) / tiles2;
     long maxs2 = (total_mt + 15) / 16;
-    long sp = want2 < 1 ? 1 : (want2 > maxs2 ? maxs2 : want2);
+    long sp = 1;
+    double best = -1.0;
+    const char* eb2 = getenv("CDDMSL_WGRAD256_BLOCKS");            // tuning knob (A/B runs): force ~this many blocks
+    for (int r = 1; r <= 6 && !eb2; ++r) {
+      long c = (256L * r) / tiles2;
+      if (c < 1) continue;
+      if (c > maxs2) c = maxs2;
+      const long blocks = tiles2 * c, rounds = (blocks + 255) / 256;
+      const double eff = (double)blocks / (256.0 * rounds);
+      if (eff > best + 0.02) { best = eff; sp = c; }
+      if (c == maxs2) break;
+    }
+    if (eb2) { sp = (atol(eb2) + tiles2 - 1) / tiles2; if (sp > maxs2) sp = maxs2; }
     if (sp < 1) sp = 1;
     int keep = a.mtiles_per_split;
     a.mtiles_per_split = (int)((total_mt + sp - 1) / sp);
