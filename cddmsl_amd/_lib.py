@@ -41,6 +41,8 @@ def stream_ptr():
 def to_device_async(cpu_tensor, device):
     """Host -> device copy that does NOT synchronise: staged through pinned memory and enqueued on the current stream
     (a pageable ``.to(device)`` blocks until everything already queued has run, i.e. acts as a full device sync)."""
+    if torch.device(device).type == "cpu":
+        return cpu_tensor
     if cpu_tensor.numel() == 0:
         return torch.empty(cpu_tensor.shape, dtype=cpu_tensor.dtype, device=device)
     return cpu_tensor.pin_memory().to(device, non_blocking=True)
@@ -65,3 +67,25 @@ def require_cuda(*tensors):
                 "cddmsl_amd ops run only on the MI355X HIP path; got a CPU tensor "
                 "(the CPU restatement lives in oracle/ and is test infrastructure only)"
             )
+
+
+class Readback:
+    """Device -> host copy whose wait covers ONLY the work enqueued before it: the copy goes to pinned memory on the current
+    stream and an event is recorded right behind it; ``get()`` blocks on that event.  A ``tensor.cpu()`` / ``.tolist()`` at the
+    point of use would instead wait for everything enqueued in between -- the idea here is to enqueue independent device work
+    (the next stage, another branch) between issuing a readback and consuming it, so the device stays busy while the host
+    does the data-dependent part (sampling permutations, list building)."""
+
+    def __init__(self, t):
+        if t.is_cuda:
+            self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self.host.copy_(t, non_blocking=True)
+            self.ev = torch.cuda.Event()
+            self.ev.record()
+        else:
+            self.host, self.ev = t, None
+
+    def get(self):
+        if self.ev is not None:
+            self.ev.synchronize()
+        return self.host

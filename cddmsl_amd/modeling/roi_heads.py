@@ -302,7 +302,7 @@ class CLIPRes5ROIHeads(nn.Module):
         return att[:k], att[k:]
 
     def forward(self, images, features, proposals, targets=None, res5=None, attnpool=None):
-        """clip_roi_heads.py:134-175 (training)."""
+        """clip_roi_heads.py:134-175"""
         assert attnpool is not None, "CLIPRes5ROIHeads is used with the backbone's attention pool (rcnn.py:606-612)"
         if self.training:
             assert targets

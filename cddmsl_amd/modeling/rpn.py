@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import hip, layers
-from .._lib import to_device_async
+from .._lib import Readback, to_device_async
 from ..registry import ANCHOR_GENERATOR_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY
 from ..structures import Boxes, Instances, as_instances
 from .backbone import to_nhwc, to_nchw
@@ -61,24 +61,30 @@ def subsample_labels(labels, num_samples, positive_fraction, bg_label, gen):
     return positive[perm1], negative[perm2]
 
 
-def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_label, gen, counts_out=None):
-    """``subsample_labels`` for a list of per-image label vectors with ONE device->host sync in total instead of two per
-    image (the per-image positive / negative counts); the per-image permutations are then drawn on the host in the
-    reference's order (image by image: positives, negatives -- sampling.py:47-48) and shipped back in one async copy."""
+def subsample_begin(label_list, bg_label):
+    """Device half of the batched ``subsample_labels``: masks, running counts, and the (asynchronous) readback of the
+    per-image positive / negative counts.  Independent device work may be enqueued before ``subsample_finish``."""
     lens = [int(l.numel()) for l in label_list]
     cat = torch.cat(label_list)
     pmask, nmask = (cat != -1) & (cat != bg_label), cat == bg_label
     offs = torch.tensor([0] + lens).cumsum(0)
-    # per-image counts: cumulative sums sampled at the image boundaries -> ONE small D2H copy (the stage's only sync);
-    # the index lists then have a known size (nonzero_static), so building them does not sync again
+    # per-image counts: cumulative sums sampled at the image boundaries -> ONE small D2H copy (the stage's only sync)
     cs = torch.stack([pmask.cumsum(0), nmask.cumsum(0)])
     ends = to_device_async((offs[1:] - 1).clamp(min=0), cat.device)
-    cnt_end = cs[:, ends].cpu() * (offs[1:] > 0)            # (an empty leading image has no last element to sample)
+    return {"n": len(label_list), "offs": offs, "pmask": pmask, "nmask": nmask, "rb": Readback(cs[:, ends]), "dev": cat.device}
+
+
+def subsample_finish(st, num_samples, positive_fraction, gen, counts_out=None):
+    """Host half: wait for the counts, draw the per-image permutations in the reference's order (image by image: positives,
+    negatives -- sampling.py:47-48), ship all index lists back in one non-blocking copy.  The index lists have a known size
+    (nonzero_static), so building them does not sync again."""
+    offs = st["offs"]
+    cnt_end = st["rb"].get() * (offs[1:] > 0)                # (an empty leading image has no last element to sample)
     cnt = torch.cat([torch.zeros(2, 1, dtype=cnt_end.dtype), cnt_end], dim=1)
-    pos_all = torch.nonzero_static(pmask, size=int(cnt[0, -1]))[:, 0]
-    neg_all = torch.nonzero_static(nmask, size=int(cnt[1, -1]))[:, 0]
+    pos_all = torch.nonzero_static(st["pmask"], size=int(cnt[0, -1]))[:, 0]
+    neg_all = torch.nonzero_static(st["nmask"], size=int(cnt[1, -1]))[:, 0]
     out = []
-    for i in range(len(label_list)):
+    for i in range(st["n"]):
         p0, p1 = int(cnt[0, i]), int(cnt[0, i + 1])
         n0, n1 = int(cnt[1, i]), int(cnt[1, i + 1])
         npos, nneg = p1 - p0, n1 - n0
@@ -89,8 +95,7 @@ def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_labe
         perm1 = torch.randperm(npos, generator=gen)[:num_pos]
         perm2 = torch.randperm(nneg, generator=gen)[:num_neg]
         out.append((perm1 + p0, perm2 + n0, int(offs[i])))
-    # one (asynchronous, pinned) H2D copy for all index lists
-    sel = to_device_async(torch.cat([o[0] for o in out] + [o[1] for o in out]), cat.device)
+    sel = to_device_async(torch.cat([o[0] for o in out] + [o[1] for o in out]), st["dev"])
     npos_sel = sum(len(o[0]) for o in out)
     sel_pos, sel_neg = sel[:npos_sel], sel[npos_sel:]
     pos_idx, neg_idx = pos_all[sel_pos], neg_all[sel_neg]
@@ -100,6 +105,11 @@ def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_labe
         a += len(p)
         b += len(n)
     return res
+
+
+def subsample_labels_batched(label_list, num_samples, positive_fraction, bg_label, gen, counts_out=None):
+    """``subsample_labels`` for a list of per-image label vectors with ONE device->host sync in total instead of two per image."""
+    return subsample_finish(subsample_begin(label_list, bg_label), num_samples, positive_fraction, gen, counts_out)
 
 
 # ------------------------------------------------------------------------------------------------ anchors
@@ -208,23 +218,31 @@ class RPN(nn.Module):
         self.storage = {}
 
     @torch.no_grad()
-    def label_and_sample_anchors(self, anchors, gt_instances):
-        """rpn.py:305-363 -> (labels int8 [N,A], matched gt boxes [N,A,4])."""
+    def label_anchors_begin(self, anchors, gt_instances):
+        """rpn.py:305-363, device half: IoU + Matcher per image, counts readback issued."""
         labels, matched = [], []
         for gi in gt_instances:
             gtb = gi.gt_boxes.tensor.float().contiguous()
             idx, lab = hip.iou_match(gtb, anchors, self.iou_thresholds, self.iou_labels, True)
             labels.append(lab)
             matched.append(torch.zeros_like(anchors) if len(gtb) == 0 else gtb[idx])
+        return labels, matched, subsample_begin(labels, 0)
+
+    @torch.no_grad()
+    def label_anchors_finish(self, labels, matched, st):
+        """host half: sample 256 anchors per image (<= 128 positive) and write the {-1, 0, 1} labels"""
         self.last_counts = []
-        picks = subsample_labels_batched(labels, self.batch_size_per_image, self.positive_fraction, 0, self.sample_generator,
-                                         self.last_counts)
+        picks = subsample_finish(st, self.batch_size_per_image, self.positive_fraction, self.sample_generator, self.last_counts)
         for lab, (pos, neg) in zip(labels, picks):
             lab.fill_(-1)
             lab[pos] = 1
             lab[neg] = 0
         self.last_pos = [pos for pos, _ in picks]
         return labels, matched
+
+    def label_and_sample_anchors(self, anchors, gt_instances):
+        """rpn.py:305-363 -> (labels int8 [N,A], matched gt boxes [N,A,4])."""
+        return self.label_anchors_finish(*self.label_anchors_begin(anchors, gt_instances))
 
     def replay_sampling_draws(self, counts):
         """Advance the sampling generator exactly as one ``label_and_sample_anchors`` call over images with these
@@ -267,10 +285,10 @@ class RPN(nn.Module):
         post = self.post_nms_topk[training]
         keep, nkeep = hip.nms(boxes, valid, self.nms_thresh, post)
         bad = (valid == 2).any() | ~torch.isfinite(keys[:, :topk]).all()
-        flags = torch.cat([nkeep, bad.to(torch.int32).view(1)])
+        rb = Readback(torch.cat([nkeep, bad.to(torch.int32).view(1)]))
 
         def finish():
-            host = flags.tolist()                                            # the one host sync of this stage
+            host = rb.get().tolist()                                         # the one host wait of this stage (an event, not a stream sync)
             if host[-1] and training:
                 raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")  # proposal_utils.py:100-105
             out = []
@@ -290,15 +308,18 @@ class RPN(nn.Module):
         lg = logits.reshape(N, -1)                # (N, Hi*Wi*A)   rpn.py:456-460
         dl = deltas.reshape(N, -1, 4)             # (N, Hi*Wi*A, 4) rpn.py:461-467 (NHWC already has (h,w,a,b) order)
         losses = {}
-        # The proposal stage (sort, decode, NMS: milliseconds of device work, no random draws) is ENQUEUED before the anchor
-        # sampling, whose host side (one D2H sync, then a CPU randperm per image over ~60 k negatives) would otherwise
-        # leave the device idle; its own host sync (the keep counts) is taken afterwards.  Results are unchanged: the two
-        # stages are independent (rpn.py:469-480 runs them in the other order).
-        finish = self.predict_proposals(lg, dl, image_sizes, hf, wf, defer=True)
+        # Order of enqueue: anchor matching (its counts readback issued) -> proposal stage (sort, decode, NMS; its keep-count
+        # readback issued) -> only then the host halves.  Each readback waits on its own event, so while the host draws the
+        # sampling permutations (~5 ms for 16 x 62 k anchors) the device works through the proposal stage.  Results are
+        # unchanged: the two stages are independent (rpn.py:469-480 runs them in the other order).
+        pending = None
         if self.training:
             assert gt_instances is not None, "RPN requires gt_instances in training!"
             anchors = self.anchor_generator.grid(hf, wf)
-            labels, matched = self.label_and_sample_anchors(anchors, gt_instances)
+            pending = self.label_anchors_begin(anchors, gt_instances)
+        finish = self.predict_proposals(lg, dl, image_sizes, hf, wf, defer=True)
+        if pending is not None:
+            labels, matched = self.label_anchors_finish(*pending)
             losses = self.losses(anchors, lg, labels, dl, matched)
         return finish(), losses
 
