@@ -84,7 +84,7 @@ class TransformerMapper(nn.Module):
                 o = layers.small_attention(a.to_queries(y, out_f32=False), a.to_keys_values(y, out_f32=False), t, H, a.scale)
                 h = h + a.project(o).view(n, t, d)
                 y = layers.layer_norm(h.view(n * t, d), lyr.norm2.weight, lyr.norm2.bias, T)
-                y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True).to(T))
+                y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True, out_f32=(T != torch.bfloat16)).to(T))
                 h = h + y.view(n, t, d)
                 continue
             # exact-f32 parity path: the same arithmetic on torch ops (the fused kernel is bf16-only)
@@ -95,7 +95,7 @@ class TransformerMapper(nn.Module):
             o = (att @ v).permute(0, 2, 1, 3).reshape(n * t, d)
             h = h + a.project(o.to(T)).view(n, t, d)
             y = layers.layer_norm(h.view(n * t, d), lyr.norm2.weight, lyr.norm2.bias, T)
-            y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True).to(T))
+            y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True, out_f32=(T != torch.bfloat16)).to(T))
             h = h + y.view(n, t, d)
         return h[:, self.clip_length:]
 
