@@ -71,17 +71,19 @@ __device__ __forceinline__ bool axis_tap(float v, int L, int& lo, int& hi, float
   return true;
 }
 
-// grid: K*ph*pw blocks; block: min(256, cch rounded) threads, each 16 B of channels (loops if C is larger)
+// grid: K*ph blocks (one RoI bin ROW each: the pw bins of a row share their y taps, and 14x fewer, longer blocks than one
+// block per bin); block: min(256, cch rounded) threads, each 16 B of channels (loops if C is larger)
 template <typename T>
 __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* dbg_grid, int N, int H, int W, int cch,
                                 int ph, int pw, float scale, int sampling_ratio, int aligned) {
-  int bin = blockIdx.x;
-  int j = bin % pw, i = (bin / pw) % ph, k = bin / (pw * ph);
+  const int i = blockIdx.x % ph, k = blockIdx.x / ph;
   RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
-  if (dbg_grid && i == 0 && j == 0 && threadIdx.x == 0) { dbg_grid[2 * k] = g.gh; dbg_grid[2 * k + 1] = g.gw; }
+  if (dbg_grid && i == 0 && threadIdx.x == 0) { dbg_grid[2 * k] = g.gh; dbg_grid[2 * k + 1] = g.gw; }
   float count = (float)max(g.gh * g.gw, 1);
   const u32x4* xb = (const u32x4*)x + (long)g.b * H * W * cch;
   constexpr int VEC = Vec<T>::VEC;
+  for (int j = 0; j < pw; ++j) {
+  const long bin = ((long)k * ph + i) * pw + j;
   for (int c = threadIdx.x; c < cch; c += blockDim.x) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (g.b >= 0 && g.b < N) {
@@ -106,7 +108,8 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* 
     }
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] /= count;
-    ((u32x4*)y)[(long)bin * cch + c] = Vec<T>::pack(acc);
+    ((u32x4*)y)[bin * cch + c] = Vec<T>::pack(acc);
+  }
   }
 }
 
@@ -245,7 +248,7 @@ extern "C" int cddmsl_roi_align_forward(const void* x, const float* rois, void* 
     return CDDMSL_ERR_ARG;
   if (K == 0) return CDDMSL_OK;   // empty inputs return correctly-shaped empties (poolers.py:221-224)
   int cch = C * es / 16;
-  long grid = (long)K * ph * pw;
+  long grid = (long)K * ph;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   int threads = cch >= 256 ? 256 : ((cch + 63) / 64) * 64;
   hipStream_t st = (hipStream_t)stream;
