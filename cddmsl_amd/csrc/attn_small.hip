@@ -3,10 +3,10 @@
 // bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 softmax.  One workgroup = one (sequence, head); three waves, wave w owns
 // query rows [32w, 32w+32) (tokens padded to 96 with zero rows, head dim = 96 = 3 MFMA tiles).
 //
-// Q, K, V (and dO, P, dS in the backward) live as row-major [96][96] bf16 images in LDS (row stride 208 B).  Every
-// product reads its operands straight from those images: an operand whose contraction index runs along the image
-// COLUMNS is read with ds_read_b128, one whose contraction index runs along the image ROWS with ds_read_b64_tr_b16
-// (transposing read) -- so no transposed copy of anything is ever made:
+// Operands live as row-major [96][96] bf16 images in LDS (row stride 208 B) when some product contracts them along their
+// ROWS (read with ds_read_b64_tr_b16, the transposing read); an operand that is only ever contracted along its COLUMNS is
+// loaded from global memory straight into MFMA fragments (Q, K in the forward; V in the backward) -- so no transposed copy
+// of anything is ever made and the LDS footprint allows 4 (forward) / 2 (backward) workgroups per CU:
 //     S  = Q K^T      (cols, cols)        O  = P V        (cols, rows)
 //     dP = dO V^T     (cols, cols)        dV = P^T dO     (rows, rows)
 //     dQ = dS K       (cols, rows)        dK = dS^T Q     (rows, rows)
@@ -39,6 +39,13 @@ __device__ __forceinline__ u32x4 frag_rows(const char* img, int col0, int kk, in
   const i16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(a0 + 4 * ARS));
   const u32x2 p0 = __builtin_bit_cast(u32x2, v0), p1 = __builtin_bit_cast(u32x2, v1);
   return u32x4{p0[0], p0[1], p1[0], p1[1]};
+}
+// the same fragment straight from global memory (rows >= t read as zero): operand rows are [t][ld] elements, 16-byte aligned
+__device__ __forceinline__ u32x4 gfrag_cols(const char* g, int ld, int t, int row0, int kk, int lane) {
+  const int row = row0 + (lane & 31);
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (row < t) v = *(const u32x4*)(g + ((long)row * ld + kk * 16 + (lane >> 5) * 8) * 2);
+  return v;
 }
 __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
@@ -82,6 +89,16 @@ __device__ __forceinline__ void store_tile(char* gp, int ld, int t, int row0, in
   }
 }
 
+// this wave's 32 image rows (row0.., those < t) -> global, 16 bytes per lane (the tiles were put there by the same wave:
+// DS operations of one wave execute in order, no barrier needed)
+__device__ __forceinline__ void rows_out(const char* img, char* gp, int ld, int t, int row0, int lane) {
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int c = it * 64 + lane, row = row0 + c / 12, ch = c % 12;
+    if (row < t) *(u32x4*)(gp + ((long)row * ld) * 2 + ch * 16) = *(const u32x4*)(img + row * ARS + ch * 16);
+  }
+}
+
 // S = scale * Q K^T for this wave's 32 query rows, masked softmax over the t valid columns -> P (f32, C layout)
 __device__ __forceinline__ void scores_softmax(const char* Qi, const char* Ki, int i0, int t, float scale, int lane, f32x16 (&P)[3]) {
 #pragma unroll
@@ -111,45 +128,92 @@ __device__ __forceinline__ void scores_softmax(const char* Qi, const char* Ki, i
   }
 }
 
-__global__ __launch_bounds__(192) void k_attn_small_fwd(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
-  char *Qi = lds, *Ki = lds + IMG, *Vi = lds + 2 * IMG, *Pi = lds + 3 * IMG;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int s = blockIdx.x / p.heads, h = blockIdx.x - s * p.heads;
-  const long row0 = (long)s * p.t;
-  stage(Qi, p.q + (row0 * p.ldq + h * AT) * 2, p.t, p.ldq, tid);
-  stage(Ki, p.k + (row0 * p.ldk + h * AT) * 2, p.t, p.ldk, tid);
-  stage(Vi, p.v + (row0 * p.ldv + h * AT) * 2, p.t, p.ldv, tid);
-  __syncthreads();
-  const int i0 = 32 * w;
-  f32x16 P[3];
-  scores_softmax(Qi, Ki, i0, p.t, p.scale, lane, P);
+// the same with Q and K fragments already in registers (loaded from global: an operand that is only ever contracted along
+// its columns needs no LDS image)
+__device__ __forceinline__ void scores_softmax_regs(const u32x4 (&qf)[6], const u32x4 (&kf)[3][6], int t, float scale, int lane, f32x16 (&P)[3]) {
 #pragma unroll
-  for (int jt = 0; jt < 3; ++jt) put_tile(Pi, i0, jt * 32, P[jt], lane);   // rows of this wave only: in-order DS, no barrier
-  char* op = p.o + (row0 * p.ldo + h * AT) * 2;
+  for (int jt = 0; jt < 3; ++jt) {
 #pragma unroll
-  for (int ct = 0; ct < 3; ++ct) {
-    f32x16 acc;
+    for (int r = 0; r < 16; ++r) P[jt][r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kk = 0; kk < 6; ++kk) mma(P[jt], qf[kk], kf[jt][kk]);
+  }
+  const int c = lane & 31;
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) mma(acc, frag_cols(Pi, i0, kk, lane), frag_rows(Vi, ct * 32, kk, lane));
-    store_tile(op, p.ldo, p.t, i0, ct * 32, acc, lane);
+  for (int g = 0; g < 16; ++g) {
+    float s[3], m = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) {
+      s[jt] = (jt * 32 + c < t) ? P[jt][g] * scale : -INFINITY;
+      m = fmaxf(m, s[jt]);
+    }
+    m = half_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) { s[jt] = __expf(s[jt] - m); sum += s[jt]; }
+    sum = half_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) P[jt][g] = s[jt] * inv;
   }
 }
 
-__global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[6 * IMG];
-  char *Qi = lds, *Ki = lds + IMG, *Vi = lds + 2 * IMG, *Di = lds + 3 * IMG, *Pi = lds + 4 * IMG, *Si = lds + 5 * IMG;
+__global__ __launch_bounds__(192) void k_attn_small_fwd(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * IMG];      // V (read along its rows for P V) and P: 39 KiB -> 4 workgroups per CU
+  char *Vi = lds, *Pi = lds + IMG;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int s = blockIdx.x / p.heads, h = blockIdx.x - s * p.heads;
   const long row0 = (long)s * p.t;
+  const int i0 = 32 * w;
+  const char* qg = p.q + (row0 * p.ldq + h * AT) * 2;
+  const char* kg = p.k + (row0 * p.ldk + h * AT) * 2;
+  u32x4 qf[6], kf[3][6];
+#pragma unroll
+  for (int kk = 0; kk < 6; ++kk) qf[kk] = gfrag_cols(qg, p.ldq, p.t, i0, kk, lane);
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt)
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) kf[jt][kk] = gfrag_cols(kg, p.ldk, p.t, jt * 32, kk, lane);
+  stage(Vi, p.v + (row0 * p.ldv + h * AT) * 2, p.t, p.ldv, tid);
+  f32x16 P[3];
+  scores_softmax_regs(qf, kf, p.t, p.scale, lane, P);
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) put_tile(Pi, i0, jt * 32, P[jt], lane);   // rows of this wave only: in-order DS, no barrier
+  __syncthreads();                                                         // V image complete
+  char* op = p.o + (row0 * p.ldo + h * AT) * 2;
+  f32x16 acc[3];
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) mma(acc[ct], frag_cols(Pi, i0, kk, lane), frag_rows(Vi, ct * 32, kk, lane));
+  }
+  // O goes out through this wave's own rows of the P image (no longer needed): whole 16-byte chunks per lane
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) put_tile(Pi, i0, ct * 32, acc[ct], lane);
+  rows_out(Pi, op, p.ldo, p.t, i0, lane);
+}
+
+__global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
+  // Images: Q, K, dO (each also contracted along its rows) and ONE image that holds P for dV and then dS for dQ / dK; V is
+  // only ever contracted along its columns (dP = dO V^T) and stays in registers.  78 KiB -> 2 workgroups per CU.
+  __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
+  char *Qi = lds, *Ki = lds + IMG, *Di = lds + 2 * IMG, *Xi = lds + 3 * IMG;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int s = blockIdx.x / p.heads, h = blockIdx.x - s * p.heads;
+  const long row0 = (long)s * p.t;
+  const int i0 = 32 * w;
+  const char* vg = p.v + (row0 * p.ldv + h * AT) * 2;
+  u32x4 vf[3][6];
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt)
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) vf[jt][kk] = gfrag_cols(vg, p.ldv, p.t, jt * 32, kk, lane);
   stage(Qi, p.q + (row0 * p.ldq + h * AT) * 2, p.t, p.ldq, tid);
   stage(Ki, p.k + (row0 * p.ldk + h * AT) * 2, p.t, p.ldk, tid);
-  stage(Vi, p.v + (row0 * p.ldv + h * AT) * 2, p.t, p.ldv, tid);
   stage(Di, p.dout + (row0 * p.ldo + h * AT) * 2, p.t, p.ldo, tid);
   __syncthreads();
-  const int i0 = 32 * w;
   f32x16 P[3], dP[3];
   scores_softmax(Qi, Ki, i0, p.t, p.scale, lane, P);
 #pragma unroll
@@ -157,7 +221,7 @@ __global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dP[jt][r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) mma(dP[jt], frag_cols(Di, i0, kk, lane), frag_cols(Vi, jt * 32, kk, lane));
+    for (int kk = 0; kk < 6; ++kk) mma(dP[jt], frag_cols(Di, i0, kk, lane), vf[jt][kk]);
   }
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -169,26 +233,43 @@ __global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
     for (int jt = 0; jt < 3; ++jt) dP[jt][g] = P[jt][g] * (dP[jt][g] - rs) * p.scale;    // dS (masked columns: P = 0)
   }
 #pragma unroll
-  for (int jt = 0; jt < 3; ++jt) { put_tile(Pi, i0, jt * 32, P[jt], lane); put_tile(Si, i0, jt * 32, dP[jt], lane); }
-  __syncthreads();                                  // dV, dK need every wave's rows of P and dS
+  for (int jt = 0; jt < 3; ++jt) put_tile(Xi, i0, jt * 32, P[jt], lane);
+  __syncthreads();                                  // dV needs every wave's rows of P
   char* dqp = p.dq + (row0 * p.ldq + h * AT) * 2;
   char* dkp = p.dk + (row0 * p.ldk + h * AT) * 2;
   char* dvp = p.dv + (row0 * p.ldv + h * AT) * 2;
+  f32x16 av[3], aq[3], ak[3];
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
-    f32x16 aq, ak, av;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ak[r] = 0.f; av[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) av[ct][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) mma(av[ct], frag_rows(Xi, i0, kk, lane), frag_rows(Di, ct * 32, kk, lane));   // dV[j] = sum_i P[i][j] dO[i]   (j0 = i0)
+  }
+  __syncthreads();                                  // every wave is done reading P: the image now takes dS
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) put_tile(Xi, i0, jt * 32, dP[jt], lane);
+  __syncthreads();
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aq[ct][r] = 0.f; ak[ct][r] = 0.f; }
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) {
-      mma(aq, frag_cols(Si, i0, kk, lane), frag_rows(Ki, ct * 32, kk, lane));     // dQ[i] = sum_j dS[i][j] K[j]
-      mma(av, frag_rows(Pi, i0, kk, lane), frag_rows(Di, ct * 32, kk, lane));     // dV[j] = sum_i P[i][j] dO[i]   (j0 = i0)
-      mma(ak, frag_rows(Si, i0, kk, lane), frag_rows(Qi, ct * 32, kk, lane));     // dK[j] = sum_i dS[i][j] Q[i]
+      mma(aq[ct], frag_cols(Xi, i0, kk, lane), frag_rows(Ki, ct * 32, kk, lane));     // dQ[i] = sum_j dS[i][j] K[j]
+      mma(ak[ct], frag_rows(Xi, i0, kk, lane), frag_rows(Qi, ct * 32, kk, lane));     // dK[j] = sum_i dS[i][j] Q[i]
     }
-    store_tile(dqp, p.ldq, p.t, i0, ct * 32, aq, lane);
-    store_tile(dvp, p.ldv, p.t, i0, ct * 32, av, lane);
-    store_tile(dkp, p.ldk, p.t, i0, ct * 32, ak, lane);
   }
+  __syncthreads();                                  // all reads of Q, K, dO done: their images carry the results out (own rows)
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    put_tile(Qi, i0, ct * 32, aq[ct], lane);
+    put_tile(Ki, i0, ct * 32, ak[ct], lane);
+    put_tile(Di, i0, ct * 32, av[ct], lane);
+  }
+  rows_out(Qi, dqp, p.ldq, p.t, i0, lane);
+  rows_out(Ki, dkp, p.ldk, p.t, i0, lane);
+  rows_out(Di, dvp, p.ldv, p.t, i0, lane);
 }
 
 int check(const AttnArgs& a, int dh, int dtype) {
