@@ -109,7 +109,7 @@ def main():
     # quantity BASELINE.json's roofline target is stated on: algorithmic 1.878 TFLOP per 800x1333 image (SURVEY.md 8(d):
     # 938.8 GMAC, query-0-only attention pool), timed outside the step timing above, rank 0's own clock
     fwd_ms = None
-    if rank == 0 and (args.height, args.width) == (800, 1333):
+    if world == 1 and (args.height, args.width) == (800, 1333):
         data = next(tr._data_loader_iter)
         tr.model.share_source_pass = False
         for _ in range(2):
@@ -124,7 +124,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
-    losses = {k: float(v) for k, v in last.items()}
+    losses = {k: float(v.detach()) for k, v in last.items()}
 
     if rank == 0:
         gb = args.batch * world
