@@ -572,12 +572,17 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5):
 
 
 @_timed("layernorm")
-def layernorm_bwd(dy, x, gamma, mean, rstd):
-    require_cuda(dy, x, gamma, mean, rstd)
+def layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=None):
+    """dx = LN'(dy); with ``accumulate_into`` (f32 [R,D], contiguous) the result is ADDED to that tensor in place and it is returned"""
+    require_cuda(dy, x, gamma, mean, rstd, accumulate_into)
     R, D = x.shape
     dy = dy.contiguous()
-    dx = torch.empty_like(x)
-    check(_L().cddmsl_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), R, D, 0, _dt(dy), stream_ptr()),
+    if accumulate_into is None:
+        dx, acc = torch.empty_like(x), 0
+    else:
+        assert accumulate_into.dtype == torch.float32 and accumulate_into.is_contiguous() and accumulate_into.shape == x.shape
+        dx, acc = accumulate_into, 1
+    check(_L().cddmsl_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), R, D, acc, _dt(dy), stream_ptr()),
           "cddmsl_layernorm_bwd")
     return dx
 

@@ -485,6 +485,35 @@ def layer_norm(x2d, gamma, beta, out_dtype):
     return LayerNormFn.apply(x2d, gamma.detach(), beta.detach(), out_dtype)
 
 
+class LayerNormSkipFn(torch.autograd.Function):
+    """Pre-norm residual helper: returns (LN(x), x).  The second output is x itself, to be used by the residual add; in the
+    backward both gradients arrive at this one node, so ``dx = d_skip + LN'(d_ln)`` is ONE kernel (LN backward accumulating
+    into the skip gradient) instead of the LN backward plus autograd's separate accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, out_dtype):
+        x = x.contiguous()
+        y, mean, rstd = hip.layernorm_fwd(x, gamma, beta, out_dtype)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        if dskip is None:
+            return hip.layernorm_bwd(dy, x, gamma, mean, rstd), None, None, None
+        # In place on the incoming skip gradient: its only other consumer is the sublayer branch hanging off the same residual
+        # add, and that branch has necessarily run already (its result is the ``dy`` in hand).
+        acc = dskip.contiguous()
+        if dy is None:
+            return acc, None, None, None
+        return hip.layernorm_bwd(dy, x, gamma, mean, rstd, accumulate_into=acc), None, None, None
+
+
+def layer_norm_skip(x2d, gamma, beta, out_dtype):
+    return LayerNormSkipFn.apply(x2d, gamma.detach(), beta.detach(), out_dtype)
+
+
 class FocalCEFn(torch.autograd.Function):
     """mean_i[ CE_i * (1 - p_t)^gamma * (bg_weight if target == bg else 1) ]   (fast_rcnn.py:624-644)"""
 

@@ -78,15 +78,16 @@ class TransformerMapper(nn.Module):
         for lyr in self.transformer.layers:
             a = lyr.attn
             H = a.num_heads
-            y = layers.layer_norm(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
             if T == torch.bfloat16 and d // H == 96 and t <= 96:
-                # throughput path: projections emit bf16, one fused attention kernel per direction, heads stay column blocks
+                # throughput path: projections emit bf16, one fused attention kernel per direction, heads stay column blocks;
+                # LayerNorm hands back its input for the residual add so that the backward accumulates in one kernel
+                y, hs = layers.layer_norm_skip(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
                 o = layers.small_attention(a.to_queries(y, out_f32=False), a.to_keys_values(y, out_f32=False), t, H, a.scale)
-                h = h + a.project(o).view(n, t, d)
-                y = layers.layer_norm(h.view(n * t, d), lyr.norm2.weight, lyr.norm2.bias, T)
-                y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True, out_f32=(T != torch.bfloat16)).to(T))
-                h = h + y.view(n, t, d)
+                h = hs + a.project(o)
+                y, hs = layers.layer_norm_skip(h, lyr.norm2.weight, lyr.norm2.bias, T)
+                h = (hs + lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True, out_f32=False))).view(n, t, d)
                 continue
+            y = layers.layer_norm(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
             # exact-f32 parity path: the same arithmetic on torch ops (the fused kernel is bf16-only)
             q = a.to_queries(y).view(n, t, H, d // H).permute(0, 2, 1, 3)
             kv = a.to_keys_values(y).view(n, t, 2, H, d // H)

@@ -309,3 +309,31 @@ def test_fast_rcnn_inference_single_image_matches_reference():
     post = detector_postprocess(inst, 333, 480)
     assert post.image_size == (333, 480) and torch.equal(post.pred_classes.cpu(), torch.from_numpy(fx["post_classes"]))
     assert torch.allclose(post.pred_boxes.tensor.cpu(), torch.from_numpy(fx["post_boxes"]), rtol=0, atol=1e-4)
+
+
+def test_layer_norm_skip_backward_accumulates_in_place():
+    """LayerNormSkipFn (pre-norm residual helper): (LN(x), x) forward, dx = d_skip + LN'(d_ln) in one accumulating kernel --
+    a two-block residual chain vs torch autograd with F.layer_norm."""
+    import torch.nn.functional as F
+    from cddmsl_amd import layers
+    g = torch.Generator().manual_seed(11)
+    R, D = 37, 768
+    h0 = torch.randn(R, D, generator=g)
+    gam, bet = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    w1, w2 = torch.randn(D, D, generator=g) * D ** -0.5, torch.randn(D, D, generator=g) * D ** -0.5
+    wout = torch.randn(R, D, generator=g)
+
+    def chain(h, ln):
+        y, hs = ln(h)
+        h = hs + y @ w1.to(h.device)
+        y, hs = ln(h)
+        return hs + torch.relu(y @ w2.to(h.device))
+
+    hr = h0.clone().requires_grad_(True)
+    (chain(hr, lambda h: (F.layer_norm(h, (D,), gam, bet), h)) * wout).sum().backward()
+    hg = h0.clone().cuda().requires_grad_(True)
+    gc, bc = gam.cuda(), bet.cuda()
+    out = chain(hg, lambda h: layers.layer_norm_skip(h, gc, bc, torch.float32))
+    (out * wout.cuda()).sum().backward()
+    err = (hg.grad.cpu() - hr.grad).abs().max() / hr.grad.abs().max()
+    assert err < 1e-4, float(err)
