@@ -68,16 +68,23 @@ class TransformerMapper(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
 
-    def forward(self, x):
-        """x [N, dim_clip] f32 -> [N, prefix_length, dim] f32   (clipcap.py:151-155)"""
+    def forward(self, x, last_only=False):
+        """x [N, dim_clip] f32 -> [N, prefix_length, dim] f32   (clipcap.py:151-155).
+        ``last_only=True`` returns only the LAST mapped token [N, dim] -- what ``v2l`` keeps (clipcap.py:714-719).  The other
+        79 outputs of the final layer are never read, so that layer then forms queries, the attention output, the
+        projection and the MLP for the last token only (keys / values still come from all tokens); same values, ~9 % less
+        mapper work."""
         T, d = self.compute_dtype, self.dim
         n = x.shape[0]
         h = self.linear(x.to(T)).view(n, self.clip_length, d)
         h = torch.cat((h, self.prefix_const.unsqueeze(0).expand(n, -1, -1)), dim=1)       # [n, 80, d] f32
         t = h.shape[1]
-        for lyr in self.transformer.layers:
+        nl = len(self.transformer.layers)
+        for li, lyr in enumerate(self.transformer.layers):
             a = lyr.attn
             H = a.num_heads
+            if last_only and li == nl - 1:
+                return self._last_token_layer(lyr, h, T)
             if T == torch.bfloat16 and d // H == 96 and t <= 96:
                 # throughput path: projections emit bf16, one fused attention kernel per direction, heads stay column blocks;
                 # LayerNorm hands back its input for the residual add so that the backward accumulates in one kernel
@@ -98,11 +105,28 @@ class TransformerMapper(nn.Module):
             y = layers.layer_norm(h.view(n * t, d), lyr.norm2.weight, lyr.norm2.bias, T)
             y = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True, out_f32=(T != torch.bfloat16)).to(T))
             h = h + y.view(n, t, d)
-        return h[:, self.clip_length:]
+        return h[:, -1] if last_only else h[:, self.clip_length:]
+
+    def _last_token_layer(self, lyr, h, T):
+        """One TransformerLayer (clipcap.py:39-100) evaluated for the last token only.  h [n, t, d] f32 -> [n, d] f32."""
+        n, t, d = h.shape
+        a = lyr.attn
+        H, dh = a.num_heads, d // a.num_heads
+        y = layers.layer_norm(h.reshape(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)           # all tokens: keys / values
+        kv = a.to_keys_values(y).view(n, t, 2, H, dh)
+        q = a.to_queries(y.view(n, t, d)[:, -1].contiguous()).view(n, H, 1, dh)                   # the one query row
+        k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)                   # [n, H, t, dh] f32
+        att = torch.softmax((q * k).sum(-1) * a.scale, dim=-1)                                    # [n, H, t]
+        o = (att.unsqueeze(-1) * v).sum(2).reshape(n, d)
+        hl = h[:, -1] + a.project(o.to(T))
+        y = layers.layer_norm(hl.contiguous(), lyr.norm2.weight, lyr.norm2.bias, T)
+        return hl + lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True).to(T))
 
 
 def v2l(prefix, model):
     """clipcap.py:714-719: the LAST of the 40 mapped tokens."""
+    if isinstance(model, TransformerMapper):
+        return model(prefix, last_only=True)
     prefix_length, size = 40, 768
     embed = model(prefix).reshape(-1, prefix_length, size)[:, -1, :]
     return embed.reshape(embed.shape[0], -1)
