@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-forward-roofline", action="store_true", help="skip the extra forward-only loop (profiling runs: keeps the kernel mix = the timed steps)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -109,7 +110,7 @@ def main():
     # quantity BASELINE.json's roofline target is stated on: algorithmic 1.878 TFLOP per 800x1333 image (SURVEY.md 8(d):
     # 938.8 GMAC, query-0-only attention pool), timed outside the step timing above, rank 0's own clock
     fwd_ms = None
-    if world == 1 and (args.height, args.width) == (800, 1333):
+    if world == 1 and (args.height, args.width) == (800, 1333) and not args.no_forward_roofline:
         data = next(tr._data_loader_iter)
         tr.model.share_source_pass = False
         for _ in range(2):
