@@ -200,3 +200,34 @@ def test_inference_and_voc_map_match_oracle(tmp_path):
         res.append(e.evaluate()["bbox"])
     for k in ("AP", "AP50", "AP75"):
         assert abs(res[0][k] - res[1][k]) <= 1e-3 * max(abs(res[1][k]), 1e-9), (k, res[0][k], res[1][k])
+
+
+def test_ragged_batch_step_matches_oracle():
+    """Images of DIFFERENT sizes in one batch (zero-padded to the batch maximum, image_list.py:72-124; proposals clipped to
+    each image's own size; the 224-crop branch pads per pair) -- all three branches, losses vs the oracle on the same inputs."""
+    from cddmsl_amd import synthetic
+    from cddmsl_amd.engine import SimpleTrainer
+    from cddmsl_amd.solver import build_optimizer
+    from oracle import model as om
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cfg = _cfg("f32")
+    model, mapper, sd, msd = _build(cfg, seed=8)
+    batch = synthetic.make_batch(1, 160, 224, num_gt=3) + synthetic.make_batch(1, 128, 192, num_gt=2, iteration=1)
+    tr = SimpleTrainer(model, iter([batch]), build_optimizer(cfg, model), cfg, clipcap_model=mapper, metrics_period=0)
+    tr.iter = 20000
+    tr.buckets.zero()
+    ld = tr.compute_losses(batch)
+    sum(ld.values()).backward()
+    got = {k: float(v.detach()) for k, v in ld.items()}
+    ocfg = _oracle_cfg(cfg, False)
+    keys = om.trainable_keys(sd, ocfg)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    ref = om.run_step_losses(sd, msd, ocfg, batch, 20000, torch.Generator().manual_seed(8))
+    sum(ref.values()).backward()
+    for k, v in ref.items():
+        assert abs(got[k] - float(v)) <= 1e-3 * abs(float(v)) + 1e-6, (k, got[k], float(v))
+    params = dict(model.named_parameters())
+    for k in keys:
+        g, r = params[k].grad.detach().float().cpu(), sd[k].grad
+        assert float((g - r).abs().max() / max(float(r.abs().max()), 1e-5)) < 5e-3, k
