@@ -231,3 +231,19 @@ def test_ragged_batch_step_matches_oracle():
     for k in keys:
         g, r = params[k].grad.detach().float().cpu(), sd[k].grad
         assert float((g - r).abs().max() / max(float(r.abs().max()), 1e-5)) < 5e-3, k
+
+
+def test_image_without_ground_truth_matches_oracle():
+    """One sample carries no ground-truth boxes (matcher.py:78-90: everything is background / ignored; roi_heads.py:262-277: all
+    sampled proposals are background, no gt_boxes field): supervised losses vs the oracle."""
+    from cddmsl_amd import synthetic
+    from oracle import model as om
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    cfg = _cfg("f32")
+    model, _, sd, _ = _build(cfg, seed=4)
+    batch = synthetic.make_batch(2, 160, 224, num_gt=3)
+    batch[1]["instances"] = {"gt_boxes": torch.zeros(0, 4), "gt_classes": torch.zeros(0, dtype=torch.int64), "image_size": (160, 224)}
+    ld = model(batch)
+    ref = om.forward(sd, _oracle_cfg(cfg, False), batch, gen=torch.Generator().manual_seed(4))
+    for k, v in ref.items():
+        assert abs(float(ld[k].detach()) - float(v)) <= 1e-3 * abs(float(v)) + 1e-6, (k, float(ld[k].detach()), float(v))
