@@ -1334,6 +1334,82 @@ __global__ void k_weight_prep(const float* w, const float* scale, char* wf, char
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 convolutions with FEW input channels (the CLIP stem: 3(->8 padded)->32 stride 2, 32->32, 32->64; one or four
+// 16-byte chunks per pixel), pad 1, FrozenBN + ReLU epilogue.  These layers are pure streaming work: K = 72 or 288,
+// N = 32 or 64, M = millions of pixels.  On the tile kernel a block ran 2-5 K-tiles behind one DMA latency each and
+// reached ~1 TB/s; here NOTHING goes through LDS: the whole weight matrix lives in registers as MFMA B fragments
+// (<= 18 k-steps x NT tiles), each wave walks 32-pixel tiles with a grid stride, and a lane's A fragment of a k-step is
+// ONE 16-byte global load (8 consecutive channels of one filter tap of its pixel; the 9 taps of neighbouring pixels hit
+// L1/L2).  All loads of a tile are issued before its MFMAs.  Output: lanes = consecutive channels (64 contiguous bytes
+// per pixel and tile).  Same accumulation order as k_conv_fwd (chunk pairs in K order) -> bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CPP, int NT>
+__global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
+  constexpr int KC = 9 * CPP, KS = (KC + 1) / 2;       // 16-byte chunks of a weight row; k-steps of two chunks
+  constexpr int ES = Mma<T>::ES;
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  // weights -> registers: B fragment of k-step ks, tile nt = chunk 2ks+hh of weight row nt*32 + r (zero past the row end)
+  u32x4 bw[NT][KS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int q = 2 * ks + hh;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q < KC) v = *(const u32x4*)(p.w + ((long)(nt * 32 + r) * KC + q) * 16);
+      bw[nt][ks] = v;
+    }
+  float sc[NT], bi[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { sc[nt] = p.scale ? p.scale[nt * 32 + r] : 1.f; bi[nt] = p.bias ? p.bias[nt * 32 + r] : 0.f; }
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int ntiles = (p.M + 31) >> 5;
+  for (int tile = wave; tile < ntiles; tile += nwaves) {
+    const int m = tile * 32 + r;
+    const bool vm = m < p.M;
+    const unsigned mm = vm ? m : 0;
+    const unsigned tq = fdiv(mm, p.dWo), ox = mm - tq * p.Wo;
+    const unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
+    const int iy0 = (int)oy * p.stride - 1, ix0 = (int)ox * p.stride - 1;
+    const char* base = p.x + (((long)img * p.Hi + iy0) * p.Wi + ix0) * (CPP * 16);
+    u32x4 a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // this lane's chunk: q = 2ks + hh -> (tap, chunk within the pixel); both alternatives are compile-time, hh selects
+      const int q0 = 2 * ks, q1 = 2 * ks + 1;
+      const int t0 = q0 / CPP, c0 = q0 % CPP, t1 = q1 / CPP, c1 = q1 % CPP;
+      const int ky = hh ? t1 / 3 : t0 / 3, kx = hh ? t1 % 3 : t0 % 3, cc = hh ? c1 : c0;
+      const bool inq = hh ? (q1 < KC) : (q0 < KC);
+      const int iy = iy0 + ky, ix = ix0 + kx;
+      const bool ok = vm && inq && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = *(const u32x4*)(base + ((long)ky * p.Wi + kx) * (CPP * 16) + cc * 16);
+      a[ks] = v;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) Mma<T>::step(acc[nt], a[ks], bw[nt][ks]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int mo = tile * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+        if (mo < p.M) {
+          float v = acc[nt][g] * sc[nt] + bi[nt];
+          if (p.relu) v = fmaxf(v, 0.f);
+          Mma<T>::store(p.y + ((long)mo * p.ldy + nt * 32 + r) * ES, v);
+        }
+      }
+  }
+}
+
 static thread_local int g_last_kernel = 0;   // which kernel the last conv/GEMM entry point of this thread launched (cddmsl_last_kernel)
 static thread_local int g_batch = 1;   // set by the batched entry point around its launch
 static inline int g_batch_peek() { return g_batch; }
@@ -1696,6 +1772,17 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   long grid = (long)ntn * ntm;
   if (grid <= 0) return CDDMSL_OK;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  // few-channel 3x3 layers (the CLIP stem): streaming register-weight kernel
+  if (!a.pool && a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.cpp == 1 || a.cpp == 4) && (a.Cout == 32 || a.Cout == 64) &&
+      !a.residual && !a.relu_mask && !a.out_f32 && g_batch == 1 && a.xrs == a.cpp && a.wrs == a.Kc) {
+    g_last_kernel = 8;
+    const int nb = 256 * 8;                       // 8 blocks of 4 waves per CU, grid-stride over 32-pixel tiles
+    if (a.cpp == 1 && a.Cout == 32) hipLaunchKernelGGL((k_conv3x3_small<T, 1, 1>), dim3(nb), dim3(256), 0, st, a);
+    else if (a.cpp == 1) hipLaunchKernelGGL((k_conv3x3_small<T, 1, 2>), dim3(nb), dim3(256), 0, st, a);
+    else if (a.Cout == 32) hipLaunchKernelGGL((k_conv3x3_small<T, 4, 1>), dim3(nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv3x3_small<T, 4, 2>), dim3(nb), dim3(256), 0, st, a);
+    return launch_status();
+  }
   if (use_gemm256(a)) {
     grid = (long)(a.Cout / 256) * ((a.M + 255) / 256);
     g_last_kernel = 3;

@@ -233,3 +233,29 @@ def test_conv_wgrad_256_tile_kernel(case, monkeypatch):
         assert err < tol, (mode, float(err))
     # same products, fp32 accumulation in a different split order
     assert (out["0"] - out["2"]).abs().max() <= 1e-4 * ref.abs().max()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("case", [(2, 37, 53, 3, 32, 2), (1, 40, 61, 32, 32, 1), (3, 21, 30, 32, 64, 1), (1, 5, 7, 3, 64, 1)])
+def test_conv3x3_small_channel_streaming_kernel(case, dtype, tol):
+    """The register-weight streaming kernel of the CLIP stem (Cin 3 -> padded pixel, or 32; Cout 32 / 64; stride 1 / 2;
+    ragged sizes) vs ATen fp32, FrozenBN + ReLU epilogue."""
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout, s = case
+    x = _rand((N, Cin, H, W), 41).to(dtype).float()
+    w = (_rand((Cout, Cin, 3, 3), 42) * (Cin * 9) ** -0.5).to(dtype).float()
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(43)) + 0.5
+    bias = _rand((Cout,), 44, 0.1)
+    ref = F.relu(F.conv2d(x, w, stride=s, padding=1) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+    cp = Cin if Cin >= 8 else (8 if dtype == torch.bfloat16 else 4)        # the 3-channel input is padded to a 16-byte pixel
+    xg = torch.zeros(N, H, W, cp)
+    xg[..., :Cin] = x.permute(0, 2, 3, 1)
+    wg = torch.zeros(Cout, 3, 3, cp)
+    wg[..., :Cin] = w.permute(0, 2, 3, 1)
+    if dtype == torch.float32 and Cin == 32:
+        pytest.skip("f32 with 32 channels is 8 chunks per pixel: the tile kernel's fast path, not this kernel")
+    wf, _ = hip.weight_prep(wg.cuda(), None, dtype, True, False)
+    y = hip.conv_fwd(xg.cuda().to(dtype), wf, scale.cuda(), bias.cuda(), relu=True, stride=s, pad=1)
+    assert hip._L().cddmsl_last_kernel() == 8
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max()
+    assert err < tol, float(err)
