@@ -1349,17 +1349,27 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
   constexpr int KC = 9 * CPP, KS = (KC + 1) / 2;       // 16-byte chunks of a weight row; k-steps of two chunks
   constexpr int ES = Mma<T>::ES;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
-  // weights -> registers: B fragment of k-step ks, tile nt = chunk 2ks+hh of weight row nt*32 + r (zero past the row end)
-  u32x4 bw[NT][KS];
+  // weights as MFMA B fragments: fragment (nt, ks) of a lane = chunk 2ks+hh of weight row nt*32 + r (zero past the row end).
+  // One chunk per pixel (K = 72): 5 k-steps, kept in registers.  Four chunks per pixel (K = 288): 18 k-steps x NT tiles would
+  // take up to 144 VGPRs and leave one wave per SIMD -- they sit in LDS in fragment order (lane-linear 16-byte reads).
+  constexpr bool WLDS = CPP > 1;
+  __shared__ __attribute__((aligned(16))) u32x4 wl[WLDS ? NT * KS * 64 : 1];
+  u32x4 bw[WLDS ? 1 : NT][WLDS ? 1 : KS];
+  {
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int q = 2 * ks + hh;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (q < KC) v = *(const u32x4*)(p.w + ((long)(nt * 32 + r) * KC + q) * 16);
-      bw[nt][ks] = v;
-    }
+      for (int ks = 0; ks < KS; ++ks) {
+        if (WLDS && ((nt * KS + ks) & 3) != wv) continue;       // the four waves fill the image cooperatively
+        const int q = 2 * ks + hh;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (q < KC) v = *(const u32x4*)(p.w + ((long)(nt * 32 + r) * KC + q) * 16);
+        if (WLDS) wl[(nt * KS + ks) * 64 + lane] = v;
+        else bw[WLDS ? 0 : nt][WLDS ? 0 : ks] = v;
+      }
+    if (WLDS) __syncthreads();
+  }
   float sc[NT], bi[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { sc[nt] = p.scale ? p.scale[nt * 32 + r] : 1.f; bi[nt] = p.bias ? p.bias[nt * 32 + r] : 0.f; }
@@ -1392,10 +1402,15 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
+    int wlane = lane;
+    asm volatile("" : "+v"(wlane));            // opaque per tile: keeps the fragment reads in the loop (hoisted, they are 144 VGPRs again)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) Mma<T>::step(acc[nt], a[ks], bw[nt][ks]);
+      for (int nt = 0; nt < NT; ++nt) {
+        if (WLDS) Mma<T>::step(acc[nt], a[ks], wl[(nt * KS + ks) * 64 + wlane]);
+        else Mma<T>::step(acc[nt], a[ks], bw[WLDS ? 0 : nt][WLDS ? 0 : ks]);
+      }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
