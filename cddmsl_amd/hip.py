@@ -479,13 +479,16 @@ def nms(boxes, valid, thr, max_keep):
 
 
 @_timed("iou_match")
-def iou_match(gt, preds, thresholds, labels, allow_low_quality):
-    """Fused pairwise_iou + Matcher for one image: gt [G,4], preds [P,4] -> (matches int64 [P], labels int8 [P])."""
+def iou_match(gt, preds, thresholds, labels, allow_low_quality, out_matches=None, out_labels=None):
+    """Fused pairwise_iou + Matcher for one image: gt [G,4], preds [P,4] -> (matches int64 [P], labels int8 [P]).
+    ``out_*``: optional contiguous destination rows (callers that batch several images write into slices of one tensor)."""
     require_cuda(gt, preds)
     G, P = gt.shape[0], preds.shape[0]
     assert gt.dtype == preds.dtype == torch.float32 and gt.is_contiguous() and preds.is_contiguous()
-    matches = torch.empty(P, device=preds.device, dtype=torch.int64)
-    lab = torch.empty(P, device=preds.device, dtype=torch.int8)
+    matches = torch.empty(P, device=preds.device, dtype=torch.int64) if out_matches is None else out_matches
+    lab = torch.empty(P, device=preds.device, dtype=torch.int8) if out_labels is None else out_labels
+    assert matches.dtype == torch.int64 and lab.dtype == torch.int8 and matches.is_contiguous() and lab.is_contiguous()
+    assert matches.numel() == P and lab.numel() == P
     best = torch.empty(max(G, 1), device=preds.device, dtype=torch.int32)
     nthr = len(thresholds)
     t0 = float(thresholds[0])

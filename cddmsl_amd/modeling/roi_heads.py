@@ -17,7 +17,7 @@ from .._lib import to_device_async
 from ..registry import ROI_HEADS_REGISTRY
 from ..structures import Boxes, Instances, ShapeSpec, as_instances
 from .backbone import to_nhwc, to_nchw
-from .rpn import apply_deltas, get_deltas, subsample_labels_batched
+from .rpn import apply_deltas, get_deltas, subsample_begin, subsample_finish, subsample_labels_batched
 
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))  # proposal_utils.py:183
 
@@ -244,36 +244,60 @@ class CLIPRes5ROIHeads(nn.Module):
 
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals: List[Instances], targets: List[Instances]):
-        """roi_heads.py:236-319 (+ add_ground_truth_to_proposals proposal_utils.py:133-200, _sample_proposals :184-234)"""
-        out, nfg, nbg = [], [], []
-        staged = []
-        for prop, tgt in zip(proposals, targets):
-            gtb = tgt.gt_boxes.tensor.float().contiguous()
-            gtc = tgt.gt_classes
-            boxes, logits = prop.proposal_boxes.tensor, prop.objectness_logits
+        """roi_heads.py:236-319 (+ add_ground_truth_to_proposals proposal_utils.py:133-200, _sample_proposals :184-234), all
+        images at once: one concatenated box / logit / class vector, per-image matching written into its slices, one
+        sampling pass, one gather per field -- ~40 small launches instead of ~12 per image."""
+        dev = proposals[0].proposal_boxes.tensor.device
+        gtbs = [t.gt_boxes.tensor.float().contiguous() for t in targets]
+        gtcs = [t.gt_classes for t in targets]
+        parts_b, parts_l, counts = [], [], []
+        for prop, gtb in zip(proposals, gtbs):
+            parts_b.append(prop.proposal_boxes.tensor)
+            parts_l.append(prop.objectness_logits)
             if self.proposal_append_gt:
-                boxes = torch.cat([boxes, gtb])
-                logits = torch.cat([logits, GT_LOGIT * torch.ones(len(gtb), device=logits.device)])
-            boxes = boxes.contiguous()
-            midx, mlab = hip.iou_match(gtb, boxes, self.iou_thresholds, self.iou_labels, False)
-            if gtc.numel() > 0:
-                cls = gtc[midx]
-                cls[mlab == 0] = self.num_classes
-                cls[mlab == -1] = -1
-            else:
-                cls = torch.zeros_like(midx) + self.num_classes
-            staged.append((prop, gtb, gtc, boxes, logits, midx, cls))
-        picks = subsample_labels_batched([st[6] for st in staged], self.batch_size_per_image, self.positive_fraction,
-                                         self.num_classes, self.sample_generator)
-        for (prop, gtb, gtc, boxes, logits, midx, cls), (fg, bg) in zip(staged, picks):
-            sidx = torch.cat([fg, bg], dim=0)
+                parts_b.append(gtb)
+                parts_l.append(torch.full((len(gtb),), GT_LOGIT, device=dev))
+            counts.append(len(prop) + (len(gtb) if self.proposal_append_gt else 0))
+        boxes_all = torch.cat(parts_b).contiguous()
+        logits_all = torch.cat(parts_l)
+        total = sum(counts)
+        midx_all = torch.empty(total, dtype=torch.int64, device=dev)
+        mlab_all = torch.empty(total, dtype=torch.int8, device=dev)
+        off = 0
+        for gtb, c in zip(gtbs, counts):
+            hip.iou_match(gtb, boxes_all[off:off + c], self.iou_thresholds, self.iou_labels, False,
+                          out_matches=midx_all[off:off + c], out_labels=mlab_all[off:off + c])
+            off += c
+        ngt = [len(g) for g in gtbs]
+        has_gt = sum(ngt) > 0
+        gt_off_rows = to_device_async(torch.repeat_interleave(torch.tensor([0] + ngt).cumsum(0)[:-1], torch.tensor(counts)), dev)
+        gidx_all = midx_all + gt_off_rows                      # row of the matched box in the concatenated ground truth
+        if has_gt:
+            gtc_cat, gtb_cat = torch.cat(gtcs), torch.cat(gtbs)
+            cls_all = gtc_cat[gidx_all.clamp(max=gtc_cat.numel() - 1)]
+            cls_all[mlab_all == 0] = self.num_classes
+            cls_all[mlab_all == -1] = -1
+            if min(ngt) == 0:                                  # images without boxes: every proposal is background (roi_heads.py:208-209)
+                nog = to_device_async(torch.repeat_interleave(torch.tensor([g == 0 for g in ngt]), torch.tensor(counts)), dev)
+                cls_all[nog] = self.num_classes
+        else:
+            cls_all = torch.full((total,), self.num_classes, dtype=torch.int64, device=dev)
+        st = subsample_begin(cls_all, self.num_classes, lens=counts)
+        st["global_only"] = True
+        subsample_finish(st, self.batch_size_per_image, self.positive_fraction, self.sample_generator)
+        fg_g, bg_g, nfg, nbg = st["global"]
+        fgs, bgs = torch.split(fg_g, nfg), torch.split(bg_g, nbg)
+        sidx = torch.cat([t for pair in zip(fgs, bgs) for t in pair])          # per image: foreground picks, then background
+        b_s, l_s, c_s = boxes_all[sidx], logits_all[sidx], cls_all[sidx]
+        g_s = gtb_cat[gidx_all[sidx].clamp(max=gtb_cat.shape[0] - 1)] if has_gt else None
+        per = [f + g for f, g in zip(nfg, nbg)]
+        out = []
+        for i, (prop, pb, pl, pc) in enumerate(zip(proposals, torch.split(b_s, per), torch.split(l_s, per), torch.split(c_s, per))):
             inst = Instances(prop.image_size)
-            inst.proposal_boxes, inst.objectness_logits, inst.gt_classes = Boxes(boxes[sidx]), logits[sidx], cls[sidx]
-            if gtc.numel() > 0:
-                inst.gt_boxes = Boxes(gtb[midx[sidx]])
-            inst._num_fg = int(fg.numel())      # host-side: the first _num_fg rows are the foreground samples
-            nfg.append(fg.numel())
-            nbg.append(bg.numel())
+            inst.proposal_boxes, inst.objectness_logits, inst.gt_classes = Boxes(pb), pl, pc
+            if ngt[i] > 0:
+                inst.gt_boxes = Boxes(torch.split(g_s, per)[i])
+            inst._num_fg = int(nfg[i])          # host-side: the first _num_fg rows are the foreground samples
             out.append(inst)
         self.storage["roi_head/num_fg_samples"] = sum(nfg) / max(len(nfg), 1)
         self.storage["roi_head/num_bg_samples"] = sum(nbg) / max(len(nbg), 1)

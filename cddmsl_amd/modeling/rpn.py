@@ -61,17 +61,21 @@ def subsample_labels(labels, num_samples, positive_fraction, bg_label, gen):
     return positive[perm1], negative[perm2]
 
 
-def subsample_begin(label_list, bg_label):
+def subsample_begin(label_list, bg_label, lens=None):
     """Device half of the batched ``subsample_labels``: masks, running counts, and the (asynchronous) readback of the
-    per-image positive / negative counts.  Independent device work may be enqueued before ``subsample_finish``."""
-    lens = [int(l.numel()) for l in label_list]
-    cat = torch.cat(label_list)
+    per-image positive / negative counts.  Independent device work may be enqueued before ``subsample_finish``.
+    ``label_list``: per-image label vectors, or (with ``lens``) ONE flat vector holding the images back to back."""
+    if lens is None:
+        lens = [int(l.numel()) for l in label_list]
+        cat = torch.cat(label_list)
+    else:
+        cat = label_list
     pmask, nmask = (cat != -1) & (cat != bg_label), cat == bg_label
     offs = torch.tensor([0] + lens).cumsum(0)
     # per-image counts: cumulative sums sampled at the image boundaries -> ONE small D2H copy (the stage's only sync)
     cs = torch.stack([pmask.cumsum(0), nmask.cumsum(0)])
     ends = to_device_async((offs[1:] - 1).clamp(min=0), cat.device)
-    return {"n": len(label_list), "offs": offs, "pmask": pmask, "nmask": nmask, "rb": Readback(cs[:, ends]), "dev": cat.device}
+    return {"n": len(lens), "offs": offs, "pmask": pmask, "nmask": nmask, "rb": Readback(cs[:, ends]), "dev": cat.device}
 
 
 def subsample_finish(st, num_samples, positive_fraction, gen, counts_out=None):
@@ -98,7 +102,10 @@ def subsample_finish(st, num_samples, positive_fraction, gen, counts_out=None):
     sel = to_device_async(torch.cat([o[0] for o in out] + [o[1] for o in out]), st["dev"])
     npos_sel = sum(len(o[0]) for o in out)
     sel_pos, sel_neg = sel[:npos_sel], sel[npos_sel:]
-    pos_idx, neg_idx = pos_all[sel_pos], neg_all[sel_neg]
+    pos_idx, neg_idx = pos_all[sel_pos], neg_all[sel_neg]         # indices into the concatenated label vector, image by image
+    st["global"] = (pos_idx, neg_idx, [len(o[0]) for o in out], [len(o[1]) for o in out])
+    if st.get("global_only"):
+        return None
     res, a, b = [], 0, 0
     for (p, n, off) in out:
         res.append((pos_idx[a:a + len(p)] - off, neg_idx[b:b + len(n)] - off))
@@ -219,29 +226,32 @@ class RPN(nn.Module):
 
     @torch.no_grad()
     def label_anchors_begin(self, anchors, gt_instances):
-        """rpn.py:305-363, device half: IoU + Matcher per image, counts readback issued."""
-        labels, matched = [], []
-        for gi in gt_instances:
-            gtb = gi.gt_boxes.tensor.float().contiguous()
-            idx, lab = hip.iou_match(gtb, anchors, self.iou_thresholds, self.iou_labels, True)
-            labels.append(lab)
-            matched.append(torch.zeros_like(anchors) if len(gtb) == 0 else gtb[idx])
-        return labels, matched, subsample_begin(labels, 0)
+        """rpn.py:305-363, device half: IoU + Matcher per image (written into rows of ONE [N, A] tensor pair), counts readback."""
+        N, A = len(gt_instances), anchors.shape[0]
+        labels = torch.empty((N, A), dtype=torch.int8, device=anchors.device)
+        midx = torch.empty((N, A), dtype=torch.int64, device=anchors.device)
+        gts = [gi.gt_boxes.tensor.float().contiguous() for gi in gt_instances]
+        for n, gtb in enumerate(gts):
+            hip.iou_match(gtb, anchors, self.iou_thresholds, self.iou_labels, True, out_matches=midx[n], out_labels=labels[n])
+        st = subsample_begin(labels.view(-1), 0, lens=[A] * N)
+        st["global_only"] = True
+        return labels, (midx, gts), st
 
     @torch.no_grad()
     def label_anchors_finish(self, labels, matched, st):
-        """host half: sample 256 anchors per image (<= 128 positive) and write the {-1, 0, 1} labels"""
+        """host half: sample 256 anchors per image (<= 128 positive) and write the {-1, 0, 1} labels (three batched fills)"""
         self.last_counts = []
-        picks = subsample_finish(st, self.batch_size_per_image, self.positive_fraction, self.sample_generator, self.last_counts)
-        for lab, (pos, neg) in zip(labels, picks):
-            lab.fill_(-1)
-            lab[pos] = 1
-            lab[neg] = 0
-        self.last_pos = [pos for pos, _ in picks]
+        subsample_finish(st, self.batch_size_per_image, self.positive_fraction, self.sample_generator, self.last_counts)
+        pos_g, neg_g, _, _ = st["global"]
+        flat = labels.view(-1)
+        flat.fill_(-1)
+        flat[pos_g] = 1
+        flat[neg_g] = 0
+        self.last_pos_global = pos_g
         return labels, matched
 
     def label_and_sample_anchors(self, anchors, gt_instances):
-        """rpn.py:305-363 -> (labels int8 [N,A], matched gt boxes [N,A,4])."""
+        """rpn.py:305-363 -> (labels int8 [N,A], (matched gt index [N,A], per-image gt boxes))."""
         return self.label_anchors_finish(*self.label_anchors_begin(anchors, gt_instances))
 
     def replay_sampling_draws(self, counts):
@@ -253,17 +263,22 @@ class RPN(nn.Module):
             torch.randperm(nneg, generator=self.sample_generator)
 
     def losses(self, anchors, logits, labels, deltas, matched):
-        """rpn.py:365-429 (+ _dense_box_regression_loss box_regression.py:229-270, smooth-L1 beta 0 = L1)."""
-        n = len(labels)
-        gl = torch.stack(labels)
+        """rpn.py:365-429 (+ _dense_box_regression_loss box_regression.py:229-270, smooth-L1 beta 0 = L1).
+        ``labels`` int8 [N, A]; ``matched`` = (matched gt index [N, A], per-image gt boxes)."""
+        gl = labels
+        n, A = gl.shape
+        midx, gts = matched
         pos = gl == 1
         self.storage["rpn/num_pos_anchors"] = pos.sum() / n
         self.storage["rpn/num_neg_anchors"] = (gl == 0).sum() / n
-        # positives = the sampled foreground picks (known index lists): no nonzero, hence no host sync here
-        img_of = torch.repeat_interleave(torch.arange(n), torch.tensor([len(pk) for pk in self.last_pos]))
-        pi = (to_device_async(img_of, gl.device), torch.cat(self.last_pos))
-        gt_d = get_deltas(anchors[pi[1]], torch.stack(matched)[pi], self.weights)
-        loc = torch.abs(deltas[pi] - gt_d).sum()
+        # positives = the sampled foreground picks (known index list, image by image in pick order): no nonzero, no host sync
+        pos_g = self.last_pos_global
+        img, a = torch.div(pos_g, A, rounding_mode="floor"), pos_g % A
+        gt_off = to_device_async(torch.tensor([0] + [len(g) for g in gts]).cumsum(0)[:-1], gl.device)
+        gt_cat = torch.cat(gts) if sum(len(g) for g in gts) else torch.zeros((1, 4), device=gl.device)
+        mbox = gt_cat[midx.view(-1)[pos_g] + gt_off[img]]          # an image without boxes has no positives, so no row of it is read
+        gt_d = get_deltas(anchors[a], mbox, self.weights)
+        loc = torch.abs(deltas.reshape(-1, 4)[pos_g] - gt_d).sum()
         valid = gl >= 0
         obj = F.binary_cross_entropy_with_logits(logits[valid], gl[valid].to(torch.float32), reduction="sum")
         norm = self.batch_size_per_image * n
