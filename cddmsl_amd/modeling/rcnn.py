@@ -16,7 +16,7 @@ from torch import nn
 from .. import hip, layers
 from .._lib import to_device_async
 from ..registry import META_ARCH_REGISTRY
-from ..structures import ImageList, as_instances
+from ..structures import Boxes, ImageList, Instances, as_instances
 from . import resnet  # noqa: F401  (registers build_resnet_backbone)
 from .backbone import build_backbone, to_nchw
 from .clipcap import v2l
@@ -197,9 +197,15 @@ class GeneralizedRCNN(nn.Module):
                     self.proposal_generator.replay_sampling_draws(shared["counts"])
                     props = shared["proposals"]
                 sel_cpu = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image] for p in props]
-                sel_dev = to_device_async(torch.cat(sel_cpu), self.device)      # one pinned, non-blocking H2D for all images
-                sel = torch.split(sel_dev, [len(s_) for s_ in sel_cpu])
-                props = [p[s] for p, s in zip(props, sel)]
+                # one pinned, non-blocking H2D of all picks (as rows of the concatenated proposal boxes) and ONE gather
+                offs = torch.tensor([0] + [len(p) for p in props]).cumsum(0)
+                pick = to_device_async(torch.cat([s_ + int(o) for s_, o in zip(sel_cpu, offs[:-1])]), self.device)
+                picked = torch.cat([p.proposal_boxes.tensor for p in props])[pick]
+                props = []
+                for size, b_ in zip(sizes, torch.split(picked, [len(s_) for s_ in sel_cpu])):
+                    inst = Instances(tuple(size))
+                    inst.proposal_boxes = Boxes(b_)
+                    props.append(inst)
             rs, rt = self.roi_heads.forward_get_features_paired(f, n, props, self.backbone.layer4, self.backbone.attnpool)
             e = self.project(v2l(torch.cat([rs, rt]), clipcap_model))
             k = rs.shape[0]

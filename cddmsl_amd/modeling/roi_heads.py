@@ -34,8 +34,8 @@ class ROIPooler(nn.Module):
         dev = feat.device
         counts = [len(b) for b in box_lists]
         # convert_boxes_to_pooler_format poolers.py:68-95: rois grouped by image, (batch_idx, x0, y0, x1, y1)
-        rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i), device=dev), b.tensor.float()], dim=1)
-                          for i, b in enumerate(box_lists)], dim=0).contiguous()
+        bidx = to_device_async(torch.repeat_interleave(torch.arange(len(counts), dtype=torch.float32), torch.tensor(counts)), dev)
+        rois = torch.cat([bidx[:, None], torch.cat([b.tensor.float() for b in box_lists])], dim=1).contiguous()
         start = to_device_async(torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32), dev)
         return layers.roi_align(feat, rois, start, self.output_size, self.scale, self.sampling_ratio, True)
 

@@ -306,12 +306,18 @@ class RPN(nn.Module):
             host = rb.get().tolist()                                         # the one host wait of this stage (an event, not a stream sync)
             if host[-1] and training:
                 raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")  # proposal_utils.py:100-105
+            # gather all images' kept boxes / scores in two launches (the counts are on the host now)
+            cnt = host[:N]
+            total_k = sum(cnt)
+            live = torch.arange(keep.shape[1], device=keep.device)[None, :] < nkeep[:, None]
+            pos = torch.nonzero_static(live.view(-1), size=total_k)[:, 0]
+            src = (keep.long() + torch.arange(N, device=keep.device)[:, None] * boxes.shape[1]).view(-1)[pos]
+            kb, ks = boxes.view(-1, 4)[src], keys[:, : boxes.shape[1]].reshape(-1)[src]
             out = []
-            for n in range(N):
-                k = keep[n, : host[n]].long()
+            for n, (b_, s_) in enumerate(zip(torch.split(kb, cnt), torch.split(ks, cnt))):
                 inst = Instances(tuple(image_sizes[n]))
-                inst.proposal_boxes = Boxes(boxes[n][k])
-                inst.objectness_logits = keys[n][k]
+                inst.proposal_boxes = Boxes(b_)
+                inst.objectness_logits = s_
                 out.append(inst)
             return out
 
