@@ -1318,9 +1318,10 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
 // Wd[cin][KH-1-ky][KW-1-kx][cout] = W[cout][ky][kx][cin] * scale[cout]
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_weight_prep(const float* w, const float* scale, char* wf, char* wd, int Cout, int KH, int KW, int Cin) {
+__device__ __forceinline__ void weight_prep_body(const float* w, const float* scale, char* wf, char* wd, int Cout, int KH, int KW, int Cin,
+                                                 long first, long stride) {
   long n = (long)Cout * KH * KW * Cin;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < n; i += stride) {
     int ci = i % Cin; long q = i / Cin;
     int kx = q % KW; q /= KW;
     int ky = q % KH; int co = q / KH;
@@ -1332,6 +1333,17 @@ __global__ void k_weight_prep(const float* w, const float* scale, char* wf, char
       Mma<T>::store(wd + j * Mma<T>::ES, v * s);
     }
   }
+}
+template <typename T>
+__global__ void k_weight_prep(const float* w, const float* scale, char* wf, char* wd, int Cout, int KH, int KW, int Cin) {
+  weight_prep_body<T>(w, scale, wf, wd, Cout, KH, KW, Cin, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+// every trainable weight of the step in ONE launch: blockIdx.y = table row {w, scale, wf, wd, Cout, KH, KW, Cin} (8 x int64)
+template <typename T>
+__global__ void k_weight_prep_multi(const long long* table) {
+  const long long* e = table + 8 * (long)blockIdx.y;
+  weight_prep_body<T>((const float*)e[0], (const float*)e[1], (char*)e[2], (char*)e[3], (int)e[4], (int)e[5], (int)e[6], (int)e[7],
+                      (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2005,6 +2017,14 @@ extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, i
   g_last_kernel = 5;
   if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+extern "C" int cddmsl_weight_prep_multi(const long long* table, int count, int dtype, void* stream) {
+  if ((dtype != 0 && dtype != 1) || count < 0 || count > 65535) return CDDMSL_ERR_ARG;
+  if (count == 0) return CDDMSL_OK;
+  if (dtype == 0) hipLaunchKernelGGL(k_weight_prep_multi<__bf16>, dim3(64, (unsigned)count), dim3(256), 0, (hipStream_t)stream, table);
+  else hipLaunchKernelGGL(k_weight_prep_multi<float>, dim3(64, (unsigned)count), dim3(256), 0, (hipStream_t)stream, table);
   return launch_status();
 }
 

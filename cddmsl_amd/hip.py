@@ -24,6 +24,7 @@ def _L():
         L.cddmsl_conv_fwd.argtypes = [vp] * 7 + [ci] * 16 + [vp]
         L.cddmsl_conv_wgrad.argtypes = [vp] * 4 + [ci] * 12 + [vp]
         L.cddmsl_weight_prep.argtypes = [vp] * 4 + [ci] * 5 + [vp]
+        L.cddmsl_weight_prep_multi.argtypes = [vp, ci, ci, vp]
         L.cddmsl_preprocess.argtypes = [vp, vp] + [ci] * 6 + [vp, vp, ci, ci, vp]
         L.cddmsl_maxpool3s2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
         L.cddmsl_upsample_zero2.argtypes = [vp] * 4 + [ci] * 5 + [vp]
@@ -213,6 +214,14 @@ def weight_prep(w_master, scale, dtype, want_fwd=True, want_dgrad=True):
     st = _L().cddmsl_weight_prep(ptr(w_master), ptr(scale), ptr(wf), ptr(wd), Cout, KH, KW, Cin, DT[dtype], stream_ptr())
     check(st, "cddmsl_weight_prep")
     return wf, wd
+
+
+@_timed("weight_prep")
+def weight_prep_multi(table, count, dtype):
+    """``table``: int64 device tensor [count, 8] = {w, scale, wf, wd pointers, Cout, KH, KW, Cin} -> all copies in one launch"""
+    require_cuda(table)
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.shape == (count, 8)
+    check(_L().cddmsl_weight_prep_multi(ptr(table), count, DT[dtype], stream_ptr()), "cddmsl_weight_prep_multi")
 
 
 # ------------------------------------------------------------------------------------------------ elementwise

@@ -9,6 +9,8 @@ Conventions
   * weight gradients are accumulated by the wgrad kernels straight into ``param.grad`` (f32, same
     memory layout as the parameter) -- the Functions return ``None`` for parameter inputs.
 """
+import weakref
+
 import torch
 
 from . import hip
@@ -46,18 +48,55 @@ def _ohwi(w):
 
 
 class PreparedWeight:
-    """Per-step cache of the T-dtype forward weights and the flipped/transposed (and BN-scaled) dgrad weights."""
+    """Per-step cache of the T-dtype forward weights and the flipped/transposed (and BN-scaled) dgrad weights.
+
+    Trainable weights register themselves; the first ``get`` of a step refreshes ALL registered weights that were used in the
+    previous step with one ``cddmsl_weight_prep_multi`` launch into their persistent buffers (instead of ~110 small launches
+    scattered through the forward pass).  Frozen weights are prepared once, individually."""
+
+    _live = weakref.WeakSet()
+    _table = None            # (signature, device int64 table, dtype)
 
     def __init__(self, param, scale=None, frozen=False):
         self.param, self.scale, self.frozen = param, scale, frozen
         self._key = None
         self._wf = self._wd = None
+        self._dtype, self._used = None, False
+        if not frozen:
+            PreparedWeight._live.add(self)
+
+    def _sig(self):
+        return (self.param.data_ptr(), 0 if self.scale is None else self.scale.data_ptr(), self._wf.data_ptr(),
+                0 if self._wd is None else self._wd.data_ptr())
+
+    @staticmethod
+    def _refresh_all(dtype):
+        """one launch for every trainable weight that has buffers of this dtype and was used last step"""
+        items = [pw for pw in PreparedWeight._live if pw._wf is not None and pw._dtype == dtype and pw._used
+                 and pw._key is not None and pw._key[2] == pw.param.data_ptr()]
+        if not items:
+            return
+        sig = tuple(pw._sig() for pw in items)
+        if PreparedWeight._table is None or PreparedWeight._table[0] != sig or PreparedWeight._table[2] != dtype:
+            rows = []
+            for pw in items:
+                Cout, KH, KW, Cin = _ohwi(pw.param).shape
+                rows.append(list(pw._sig()) + [Cout, KH, KW, Cin])
+            from ._lib import to_device_async
+            PreparedWeight._table = (sig, to_device_async(torch.tensor(rows, dtype=torch.int64), items[0].param.device), dtype)
+        hip.weight_prep_multi(PreparedWeight._table[1], len(items), dtype)
+        for pw in items:
+            pw._key = (dtype, _STEP[0], pw.param.data_ptr())
+            pw._used = False
 
     def get(self, dtype, need_dgrad=True):
         key = (dtype, -1 if self.frozen else _STEP[0], self.param.data_ptr())
+        if key != self._key and not self.frozen and self._wf is not None and self._dtype == dtype:
+            PreparedWeight._refresh_all(dtype)        # first stale weight of the step: bring every registered weight up to date
         if key != self._key or (need_dgrad and self._wd is None):
             wf, wd = hip.weight_prep(_ohwi(self.param.detach()), self.scale, dtype, True, need_dgrad)
-            self._wf, self._wd, self._key = wf, (wd if need_dgrad else None), key
+            self._wf, self._wd, self._key, self._dtype = wf, (wd if need_dgrad else None), key, dtype
+        self._used = True
         return self._wf, self._wd
 
 

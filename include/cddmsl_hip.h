@@ -54,6 +54,9 @@ int cddmsl_last_kernel(void);
 /* f32 master -> `dtype` forward weights and flipped/transposed dgrad weights scaled by the FrozenBN scale */
 int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int Cout, int KH, int KW, int Cin,
                        int dtype, void* stream);
+/* the same for `count` weights in one launch; device table of 8 x int64 per weight: {w, scale, w_fwd, w_dgrad (pointers, 0 = skip),
+ * Cout, KH, KW, Cin}.  Used once per step after the optimizer update. */
+int cddmsl_weight_prep_multi(const long long* table, int count, int dtype, void* stream);
 
 /* ---- RoIAlign  (layers/roi_align.py:49-65 -> torchvision.ops.roi_align; modeling/poolers.py:190-229) --------- */
 int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, int* dbg_grid, int N, int C, int H, int W, int K,

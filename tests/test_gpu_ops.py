@@ -337,3 +337,33 @@ def test_layer_norm_skip_backward_accumulates_in_place():
     (out * wout.cuda()).sum().backward()
     err = (hg.grad.cpu() - hr.grad).abs().max() / hr.grad.abs().max()
     assert err < 1e-4, float(err)
+
+
+def test_prepared_weights_refresh_in_one_launch_after_update():
+    """PreparedWeight: after the optimizer bumps the weight version, the first ``get`` refreshes every registered weight
+    (cddmsl_weight_prep_multi) into its persistent buffers -- forward and flipped / BN-scaled dgrad copies follow the masters."""
+    from cddmsl_amd import layers
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.nn.Parameter(torch.randn(16, 8, 3, 3, generator=g).cuda().contiguous(memory_format=torch.channels_last)),
+          torch.nn.Parameter(torch.randn(24, 16, generator=g).cuda())]
+    scale = (torch.rand(16, generator=g) + 0.5).cuda()
+    pws = [layers.PreparedWeight(ws[0], scale), layers.PreparedWeight(ws[1], None)]
+
+    def expect(w, sc):
+        o = layers._ohwi(w.detach())
+        wd = o.flip(1, 2).permute(3, 1, 2, 0) * (sc if sc is not None else 1.0)
+        return o.bfloat16(), wd.contiguous().bfloat16()
+
+    for rnd in range(3):
+        outs = [pw.get(torch.bfloat16, True) for pw in pws]
+        for (wf, wd), w, sc in zip(outs, ws, (scale, None)):
+            ef, ed = expect(w, sc)
+            assert torch.equal(wf, ef) and torch.equal(wd, ed), rnd
+        ptrs = [(o[0].data_ptr(), o[1].data_ptr()) for o in outs]
+        if rnd:
+            assert ptrs == last_ptrs                      # persistent buffers, refreshed in place
+        last_ptrs = ptrs
+        with torch.no_grad():
+            for w in ws:
+                w.add_(0.25)
+        layers.bump_weight_version()
