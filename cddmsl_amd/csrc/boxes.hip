@@ -204,6 +204,60 @@ __global__ void k_match2(const float* gt, int G, const float* preds, int P, sign
   if (hit) labels[j] = 1;
 }
 
+// batched over images (blockIdx.y = image): gt rows gt_off[n]..gt_off[n+1]; predictions either shared by all images
+// (pred_off == nullptr: the anchors; outputs laid out [N][P]) or concatenated with offsets pred_off (proposals)
+__global__ void k_match1_batched(const float* gt, const int* gt_off, const float* preds, const int* pred_off, int P, long* matches,
+                                 signed char* labels, unsigned int* best_gt, int nthr, float t0, float t1, int l0, int l1, int l2) {
+  extern __shared__ float sg[];
+  const int n = blockIdx.y, g0 = gt_off[n], G = gt_off[n + 1] - g0;
+  const int p0 = pred_off ? pred_off[n] : 0, Pn = pred_off ? pred_off[n + 1] - p0 : P;
+  const long o0 = pred_off ? p0 : (long)n * P;
+  if (blockIdx.x * blockDim.x >= Pn) return;                 // whole block past this image's predictions (uniform)
+  for (int i = threadIdx.x; i < G * 4; i += blockDim.x) sg[i] = gt[4 * (long)g0 + i];
+  __syncthreads();
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = j < Pn;
+  long jj = live ? p0 + j : p0;
+  float x0 = preds[4 * jj], y0 = preds[4 * jj + 1], x1 = preds[4 * jj + 2], y1 = preds[4 * jj + 3];
+  float ap = (x1 - x0) * (y1 - y0);
+  float best = -1.f; int arg = 0;
+  for (int g = 0; g < G; ++g) {
+    float v = iou_pair(sg + 4 * g, x0, y0, x1, y1, ap);
+    if (v > best) { best = v; arg = g; }
+    if (best_gt) {
+      float wm = wave_max(live ? v : 0.f);
+      if ((threadIdx.x & 63) == 0) atomicMax(best_gt + g0 + g, __float_as_uint(wm));
+    }
+  }
+  if (!live) return;
+  int lab;
+  if (nthr == 1) lab = best < t0 ? l0 : l1;
+  else lab = best < t0 ? l0 : (best < t1 ? l1 : l2);
+  matches[o0 + j] = arg;
+  labels[o0 + j] = (signed char)lab;
+}
+__global__ void k_match2_batched(const float* gt, const int* gt_off, const float* preds, const int* pred_off, int P,
+                                 signed char* labels, const unsigned int* best_gt) {
+  extern __shared__ float sg[];
+  const int n = blockIdx.y, g0 = gt_off[n], G = gt_off[n + 1] - g0;
+  const int p0 = pred_off ? pred_off[n] : 0, Pn = pred_off ? pred_off[n + 1] - p0 : P;
+  const long o0 = pred_off ? p0 : (long)n * P;
+  if (blockIdx.x * blockDim.x >= Pn) return;
+  for (int i = threadIdx.x; i < G * 4; i += blockDim.x) sg[i] = gt[4 * (long)g0 + i];
+  __syncthreads();
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Pn) return;
+  long jj = p0 + j;
+  float x0 = preds[4 * jj], y0 = preds[4 * jj + 1], x1 = preds[4 * jj + 2], y1 = preds[4 * jj + 3];
+  float ap = (x1 - x0) * (y1 - y0);
+  bool hit = false;
+  for (int g = 0; g < G; ++g) {
+    float v = iou_pair(sg + 4 * g, x0, y0, x1, y1, ap);
+    hit |= (__float_as_uint(v) == best_gt[g0 + g]);
+  }
+  if (hit) labels[o0 + j] = 1;
+}
+
 }  // namespace
 
 extern "C" int cddmsl_anchors(const float* cell, float* out, int Hf, int Wf, int A, float stride, float offset, void* stream) {
@@ -274,5 +328,23 @@ extern "C" int cddmsl_iou_match(const float* gt, int G, const float* preds, int 
   size_t sh = sizeof(float) * 4 * G;
   k_match1<<<grid, block, sh, st>>>(gt, G, preds, P, matches, labels, bw, nthr, t0, t1, l0, l1, l2);
   if (allow_low_quality) k_match2<<<grid, block, sh, st>>>(gt, G, preds, P, labels, bw);
+  return launch_status();
+}
+
+// All images in one launch (pair): gt [sum G][4] with offsets gt_off [N+1] (device ints); preds [P][4] shared by all images
+// (pred_off == NULL; outputs [N][P]) or [sum P][4] with offsets pred_off [N+1] (outputs [sum P]); P = the largest per-image
+// prediction count, maxG the largest per-image box count, totalG = sum G.  An image without boxes gets labels l0, match 0.
+extern "C" int cddmsl_iou_match_batched(const float* gt, const int* gt_off, const float* preds, const int* pred_off, long* matches,
+                                        signed char* labels, unsigned int* best_ws, int N, int P, int maxG, int totalG, int nthr,
+                                        float t0, float t1, int l0, int l1, int l2, int allow_low_quality, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (N < 0 || P < 0 || maxG < 0 || totalG < 0 || nthr < 1 || nthr > 2 || maxG > 4096) return CDDMSL_ERR_ARG;
+  if (N == 0 || P == 0) return CDDMSL_OK;
+  unsigned int* bw = (allow_low_quality && totalG > 0) ? best_ws : nullptr;
+  if (bw && hipMemsetAsync(bw, 0, sizeof(unsigned int) * totalG, st) != hipSuccess) return CDDMSL_ERR_LAUNCH;
+  dim3 grid((P + 255) / 256, N), block(256);
+  size_t sh = sizeof(float) * 4 * (maxG > 0 ? maxG : 1);
+  k_match1_batched<<<grid, block, sh, st>>>(gt, gt_off, preds, pred_off, P, matches, labels, bw, nthr, t0, t1, l0, l1, l2);
+  if (bw) k_match2_batched<<<grid, block, sh, st>>>(gt, gt_off, preds, pred_off, P, labels, bw);
   return launch_status();
 }

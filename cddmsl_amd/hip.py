@@ -47,6 +47,7 @@ def _L():
         L.cddmsl_rpn_decode.argtypes = [vp] * 6 + [ci] * 5 + [cf] * 8 + [vp]
         L.cddmsl_nms.argtypes = [vp] * 5 + [ci, ci, cf, ci, vp]
         L.cddmsl_iou_match.argtypes = [vp, ci, vp, ci, vp, vp, vp, ci, cf, cf, ci, ci, ci, ci, vp]
+        L.cddmsl_iou_match_batched.argtypes = [vp] * 7 + [ci] * 5 + [cf, cf] + [ci] * 4 + [vp]
         L.cddmsl_l2norm_fwd.argtypes = [vp, vp, vp, c_long, ci, cf, vp]
         L.cddmsl_l2norm_bwd.argtypes = [vp, vp, vp, vp, c_long, ci, vp]
         L.cddmsl_cosine_logits_fwd.argtypes = [vp] * 4 + [c_long, ci, ci, cf, cf, vp]
@@ -505,6 +506,38 @@ def iou_match(gt, preds, thresholds, labels, allow_low_quality, out_matches=None
     l = list(labels) + [0]
     check(_L().cddmsl_iou_match(ptr(gt), G, ptr(preds), P, ptr(matches), ptr(lab), ptr(best), nthr, t0, t1, l[0], l[1], l[2],
                                  int(allow_low_quality), stream_ptr()), "cddmsl_iou_match")
+    return matches, lab
+
+
+@_timed("iou_match")
+def iou_match_batched(gt_list, preds, pred_counts, thresholds, labels, allow_low_quality):
+    """Fused pairwise_iou + Matcher for ALL images in one launch pair.  ``gt_list``: per-image [G_i, 4] f32 tensors;
+    ``preds``: [P, 4] shared by every image (``pred_counts`` None; returns [N, P] tensors) or the images' predictions
+    concatenated [sum P_i, 4] with ``pred_counts`` = [P_i] (returns [sum P_i] tensors)."""
+    from ._lib import to_device_async
+    require_cuda(preds, *gt_list)
+    dev = preds.device
+    N = len(gt_list)
+    ng = [int(g.shape[0]) for g in gt_list]
+    total_g = sum(ng)
+    gt = torch.cat(gt_list).float().contiguous() if total_g else torch.zeros((1, 4), device=dev)
+    gt_off = to_device_async(torch.tensor([0] + ng, dtype=torch.int32).cumsum(0).to(torch.int32), dev)
+    assert preds.dtype == torch.float32 and preds.is_contiguous()
+    if pred_counts is None:
+        P, pred_off, shape = preds.shape[0], None, (N, preds.shape[0])
+    else:
+        P, shape = max(pred_counts) if pred_counts else 0, (sum(pred_counts),)
+        pred_off = to_device_async(torch.tensor([0] + list(pred_counts), dtype=torch.int32).cumsum(0).to(torch.int32), dev)
+    matches = torch.empty(shape, device=dev, dtype=torch.int64)
+    lab = torch.empty(shape, device=dev, dtype=torch.int8)
+    best = torch.empty(max(total_g, 1), device=dev, dtype=torch.int32)
+    nthr = len(thresholds)
+    t0 = float(thresholds[0])
+    t1 = float(thresholds[1]) if nthr > 1 else 0.0
+    l = list(labels) + [0]
+    check(_L().cddmsl_iou_match_batched(ptr(gt), ptr(gt_off), ptr(preds), ptr(pred_off), ptr(matches), ptr(lab), ptr(best), N, P,
+                                         max(ng) if ng else 0, total_g, nthr, t0, t1, l[0], l[1], l[2], int(allow_low_quality),
+                                         stream_ptr()), "cddmsl_iou_match_batched")
     return matches, lab
 
 

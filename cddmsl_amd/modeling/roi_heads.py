@@ -261,13 +261,7 @@ class CLIPRes5ROIHeads(nn.Module):
         boxes_all = torch.cat(parts_b).contiguous()
         logits_all = torch.cat(parts_l)
         total = sum(counts)
-        midx_all = torch.empty(total, dtype=torch.int64, device=dev)
-        mlab_all = torch.empty(total, dtype=torch.int8, device=dev)
-        off = 0
-        for gtb, c in zip(gtbs, counts):
-            hip.iou_match(gtb, boxes_all[off:off + c], self.iou_thresholds, self.iou_labels, False,
-                          out_matches=midx_all[off:off + c], out_labels=mlab_all[off:off + c])
-            off += c
+        midx_all, mlab_all = hip.iou_match_batched(gtbs, boxes_all, counts, self.iou_thresholds, self.iou_labels, False)
         ngt = [len(g) for g in gtbs]
         has_gt = sum(ngt) > 0
         gt_off_rows = to_device_async(torch.repeat_interleave(torch.tensor([0] + ngt).cumsum(0)[:-1], torch.tensor(counts)), dev)

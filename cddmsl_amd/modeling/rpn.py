@@ -228,11 +228,8 @@ class RPN(nn.Module):
     def label_anchors_begin(self, anchors, gt_instances):
         """rpn.py:305-363, device half: IoU + Matcher per image (written into rows of ONE [N, A] tensor pair), counts readback."""
         N, A = len(gt_instances), anchors.shape[0]
-        labels = torch.empty((N, A), dtype=torch.int8, device=anchors.device)
-        midx = torch.empty((N, A), dtype=torch.int64, device=anchors.device)
         gts = [gi.gt_boxes.tensor.float().contiguous() for gi in gt_instances]
-        for n, gtb in enumerate(gts):
-            hip.iou_match(gtb, anchors, self.iou_thresholds, self.iou_labels, True, out_matches=midx[n], out_labels=labels[n])
+        midx, labels = hip.iou_match_batched(gts, anchors, None, self.iou_thresholds, self.iou_labels, True)     # [N, A] each
         st = subsample_begin(labels.view(-1), 0, lens=[A] * N)
         st["global_only"] = True
         return labels, (midx, gts), st

@@ -81,6 +81,12 @@ int cddmsl_iou_match(const float* gt, int G, const float* preds, int P, long* ma
                      unsigned int* best_ws, int nthr, float t0, float t1, int l0, int l1, int l2, int allow_low_quality,
                      void* stream);
 
+/* the same for all images of a batch in one launch pair: boxes concatenated with offsets gt_off[N+1]; predictions shared by all
+ * images (pred_off NULL: the anchors, outputs [N][P]) or concatenated with offsets pred_off[N+1] (proposals, outputs [sum P]) */
+int cddmsl_iou_match_batched(const float* gt, const int* gt_off, const float* preds, const int* pred_off, long* matches,
+                             signed char* labels, unsigned int* best_ws, int N, int P, int maxG, int totalG, int nthr, float t0,
+                             float t1, int l0, int l1, int l2, int allow_low_quality, void* stream);
+
 /* ---- CLIP attention pool (modeling/backbone/clip_backbone.py:83-107): token build/backward; the query-0 attention itself is
  * reassociated into the batched GEMMs above (cddmsl_amd/layers.py::AttnPoolFn) ------------------------------------- */
 int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int TP, int C, int dtype, void* stream);

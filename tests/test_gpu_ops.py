@@ -367,3 +367,31 @@ def test_prepared_weights_refresh_in_one_launch_after_update():
             for w in ws:
                 w.add_(0.25)
         layers.bump_weight_version()
+
+
+def test_iou_match_batched_equals_per_image():
+    """cddmsl_iou_match_batched (all images in one launch pair) vs the per-image entry point: bit-identical matches and
+    labels, shared predictions (anchors, low-quality matches on) and concatenated predictions (proposals), incl. an image
+    without boxes."""
+    from cddmsl_amd import hip
+    g = torch.Generator().manual_seed(5)
+
+    def boxes(n):
+        c = torch.rand(n, 2, generator=g) * 200
+        wh = torch.rand(n, 2, generator=g) * 80 + 4
+        return torch.cat([c, c + wh], 1).cuda()
+
+    gts = [boxes(3), boxes(0), boxes(7), boxes(1)]
+    anchors = boxes(1500)
+    m, l = hip.iou_match_batched(gts, anchors, None, [0.3, 0.7], [0, -1, 1], True)
+    for n, gt in enumerate(gts):
+        m1, l1 = hip.iou_match(gt.contiguous(), anchors, [0.3, 0.7], [0, -1, 1], True)
+        assert torch.equal(m[n], m1) and torch.equal(l[n], l1), n
+    counts = [300, 1, 517, 256]
+    props = [boxes(c) for c in counts]
+    m, l = hip.iou_match_batched(gts, torch.cat(props).contiguous(), counts, [0.5], [0, 1], False)
+    off = 0
+    for n, (gt, pr) in enumerate(zip(gts, props)):
+        m1, l1 = hip.iou_match(gt.contiguous(), pr.contiguous(), [0.5], [0, 1], False)
+        assert torch.equal(m[off:off + counts[n]], m1) and torch.equal(l[off:off + counts[n]], l1), n
+        off += counts[n]
