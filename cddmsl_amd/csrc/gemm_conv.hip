@@ -1082,6 +1082,132 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_stream(WgradArgs p, int nbat
 }
 
 // ------------------------------------------------------------------------------------------------
+// Compact streaming TN GEMM for the attention pool's per-region products when the whole reduction is ONE tile
+// (M <= 64 rows) and the output is narrow (N <= 64): out_b[n][k] = sum_m A_b[m][n] B_b[m][k], bf16.
+// k_gemm_tn_stream spends a 16 KiB LDS image per stage on an A operand of 2-7 KiB and keeps one stage in flight per
+// block; these products are pure streaming (2.9 GB per call), so what matters is bytes in flight.  Here a stage is a
+// compact A image (64 rows x 128 B) + the B image (64 rows x 256 B) = 24 KiB, three stages form a ring (two in flight,
+// counted vmcnt(12)), two blocks fit a CU.  Block = one 128-column k-tile for a run of batches; wave w owns columns
+// 32w..32w+31 for all (one or two) 32-row n-tiles.  Both operands are read transposed (ds_read_b64_tr_b16).
+// vmcnt counts stores too and retires in issue order, so the wait for stage `it` has to allow for the previous item's
+// output stores that sit between the DMAs: N = 8*NG is a template parameter and K % 128 == 0 so that this count (4*NG
+// store instructions per wave and item) is a compile-time constant.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int NG, int MODE>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_small(WgradArgs p, int nbatch, int bpb) {
+  constexpr int NTN = (NG + 3) / 4, NSTORE = 4 * NG;
+  constexpr int STAGE = 8192 + 16384, NST = 3;
+  __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int k0 = blockIdx.x * 128;
+  const int b0 = blockIdx.y * bpb, nit = min(bpb, nbatch - b0);
+  const char* zp = (const char*)g_zero_page;
+  // DMA slots: A image chunk q = i*256 + t -> row q>>3, chunk q&7 (plain); B image chunk q -> row q>>4, slot q&15 (chunk ^= fsw(row))
+  const int ar = t >> 3, ac = t & 7;
+  const bool va = ac * 8 < p.Cout;
+  const int xr = t >> 4, xc = (t & 15) ^ fsw(t >> 4);
+  const int kc = (k0 >> 3) + xc;
+  const bool vk = kc < p.Kc;
+  int sb = 0;
+  auto stage = [&](int slot) {
+    char* base = lds + slot * STAGE;
+    const char* db = p.dy + (long)(b0 + sb) * p.bd + ac * 16;
+    const char* xb = p.x + (long)(b0 + sb) * p.bx + (long)kc * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = ar + 32 * i;
+      glds16((va && m < p.M) ? db + ((long)m * p.ldd) * 2 : zp, base + (i * 256 + wvu * 64) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = xr + 16 * i;
+      glds16((vk && m < p.M) ? xb + ((long)m * p.xrs) * 16 : zp, base + 8192 + (i * 256 + wvu * 64) * 16);
+    }
+    ++sb;
+  };
+  f32x16 acc[NTN];
+#pragma unroll
+  for (int a = 0; a < NTN; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  // transposed-read addresses inside a stage
+  const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  unsigned aoff[NTN][2], xoff[2];
+  {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3, hh = g >> 1;
+#pragma unroll
+    for (int a = 0; a < NTN; ++a) {
+      const int col = a * 32 + 16 * (g & 1) + 4 * pp;
+      aoff[a][0] = (8 * hh + q) * 128 + col * 2;
+      aoff[a][1] = aoff[a][0] + 4 * 128;
+    }
+    const TrFragS<__bf16>::Off o = TrFragS<__bf16>::prep(wvu * 32, lane);
+    xoff[0] = 8192 + o.o0; xoff[1] = 8192 + o.o1;
+  }
+  const int r = lane & 31, h = lane >> 5;
+  if (nit > 0) stage(0);
+  if (nit > 1) stage(1);
+  for (int it = 0; it < nit; ++it) {
+    const int slot = it % NST;
+    // younger than stage `it`: stage it+1 (6 DMAs), the stores of item it-1, stage it+2 (6 DMAs)
+    if (it + 2 < nit) {
+      stage((it + 2) % NST);
+      if (it) wait_vm<12 + NSTORE>(); else wait_vm<12>();
+    } else if (it + 1 < nit) {
+      if (it) wait_vm<6 + NSTORE>(); else wait_vm<6>();
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const unsigned sbase = lbase + slot * STAGE;
+#define CDDMSL_TRS(DST, A0, A1, IMM)                                                             \
+  { u32x2 q0_, q1_;                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q0_) : "v"(A0), "i"(IMM));         \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(q1_) : "v"(A1), "i"(IMM));         \
+    DST = u32x4{q0_[0], q0_[1], q1_[0], q1_[1]}; }
+    u32x4 fa[NTN][4], fb[4];
+    const unsigned x0 = sbase + xoff[0], x1 = sbase + xoff[1];
+    CDDMSL_TRS(fb[0], x0, x1, 0) CDDMSL_TRS(fb[1], x0, x1, 4096) CDDMSL_TRS(fb[2], x0, x1, 8192) CDDMSL_TRS(fb[3], x0, x1, 12288)
+#pragma unroll
+    for (int a = 0; a < NTN; ++a) {
+      const unsigned a0 = sbase + aoff[a][0], a1 = sbase + aoff[a][1];
+      CDDMSL_TRS(fa[a][0], a0, a1, 0) CDDMSL_TRS(fa[a][1], a0, a1, 2048) CDDMSL_TRS(fa[a][2], a0, a1, 4096) CDDMSL_TRS(fa[a][3], a0, a1, 6144)
+    }
+#undef CDDMSL_TRS
+    if (NTN == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fa[0][0]), "+v"(fa[0][1]),
+                               "+v"(fa[0][2]), "+v"(fa[0][3]) :: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]), "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]),
+                      "+v"(fa[0][3]), "+v"(fa[NTN - 1][0]), "+v"(fa[NTN - 1][1]), "+v"(fa[NTN - 1][2]), "+v"(fa[NTN - 1][3]) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms)
+#pragma unroll
+      for (int a = 0; a < NTN; ++a) Mma<__bf16>::step(acc[a], fa[a][ms], fb[ms]);
+    __builtin_amdgcn_s_barrier();                    // every wave is done with this slot before the next iteration restages it
+    char* outp = (char*)p.dw + (long)(b0 + it) * p.bo;
+    const int k = k0 + wvu * 32 + r;
+#pragma unroll
+    for (int a = 0; a < NTN; ++a)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        if (a * 4 + (g >> 2) < NG) {                 // rows 8*(4a + g/4) .. +7 exist: exactly NSTORE stores per item
+          const int n = a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+          const float v = acc[a][g];
+          const long o = (long)n * p.ldo + k;
+          if (MODE == 0) atomicAdd((float*)outp + o, v);
+          else if (MODE == 1) ((float*)outp)[o] = v;
+          else Mma<__bf16>::store(outp + o * 2, v);
+        }
+        acc[a][g] = 0.f;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad / TN GEMM on the 256x256 ping-pong structure of k_conv_fwd256 (bf16): output tile 256 n x 256 k, reduction
 // tiles of 64 m rows, 8 waves (2 over n x 4 over k; 128 n x 64 k per wave), the two wave groups one barrier apart.
 // Operands stay row-major in LDS ([64 rows][256 B] images, chunk ^= fsw(row)) and are read transposed
@@ -1998,6 +2124,24 @@ extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, i
     long maxs = (total_mt + 7) / 8;
     splits = want < 1 ? 1 : (want > maxs ? maxs : want);
     if (splits < 1) splits = 1;
+  }
+  if (dtype == 0 && total_mt == 1 && N <= 64 && batch >= 64 && K % 128 == 0 && N % 8 == 0) {
+    // one reduction tile, narrow output (the attention pool's per-region products): compact three-stage ring
+    const long kt = K / 128;
+    long bpb = (kt * batch + 4095) / 4096;
+    if (bpb < 8) bpb = 8;
+    if (bpb > batch) bpb = batch;
+    const unsigned gy = (unsigned)((batch + bpb - 1) / bpb);
+    g_last_kernel = 9;
+#define CDDMSL_TNS(NG)                                                                                                               \
+  case NG:                                                                                                                           \
+    if (mode == 0) hipLaunchKernelGGL((k_gemm_tn_small<NG, 0>), dim3((unsigned)kt, gy), dim3(256), 0, (hipStream_t)stream, p, batch, (int)bpb);      \
+    else if (mode == 1) hipLaunchKernelGGL((k_gemm_tn_small<NG, 1>), dim3((unsigned)kt, gy), dim3(256), 0, (hipStream_t)stream, p, batch, (int)bpb); \
+    else hipLaunchKernelGGL((k_gemm_tn_small<NG, 2>), dim3((unsigned)kt, gy), dim3(256), 0, (hipStream_t)stream, p, batch, (int)bpb);                \
+    break;
+    switch (N / 8) { CDDMSL_TNS(1) CDDMSL_TNS(2) CDDMSL_TNS(3) CDDMSL_TNS(4) CDDMSL_TNS(5) CDDMSL_TNS(6) CDDMSL_TNS(7) CDDMSL_TNS(8) }
+#undef CDDMSL_TNS
+    return launch_status();
   }
   if (total_mt <= 4 && batch >= 64) {
     // short reductions over many batches: stream runs of batches through one block (k_gemm_tn_stream)

@@ -142,6 +142,23 @@ def test_batched_gemms(dtype, tol):
         hip.gemm_tn_batched(Pm.cuda(), Tn.cuda(), Z, Mm, 32, 256, 32, 256, 256, Bn, Mm * 32, Mm * 256, 32 * 256)
         ref = torch.bmm(Pm.float().transpose(1, 2), Tn.float())
         assert (Z.float().cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    # one-tile reductions with a narrow output take the compact three-stage ring (bf16): every row-group count of the
+    # template (N = 8..64), a 3-row reduction, bf16 / f32 stores and f32 accumulation, runs shorter than the ring
+    if dtype == torch.bfloat16:
+        for Bn, Mm, Nn, Kk in ((150, 64, 56, 384), (64, 3, 8, 128), (201, 50, 64, 256), (90, 33, 24, 128), (67, 17, 40, 128),
+                               (129, 64, 48, 256), (70, 9, 16, 128)):
+            Pm = torch.randn(Bn, Mm, Nn, generator=g).to(dtype)
+            Tn = torch.randn(Bn, Mm, Kk, generator=g).to(dtype)
+            ref = torch.bmm(Pm.float().transpose(1, 2), Tn.float())
+            Z = torch.zeros(Bn, Nn, Kk, dtype=dtype).cuda()
+            hip.gemm_tn_batched(Pm.cuda(), Tn.cuda(), Z, Mm, Nn, Kk, Nn, Kk, Kk, Bn, Mm * Nn, Mm * Kk, Nn * Kk)
+            assert hip._L().cddmsl_last_kernel() == 9
+            assert (Z.float().cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max())), (Bn, Mm, Nn, Kk)
+            Zf = torch.full((Bn, Nn, Kk), 2.0, dtype=torch.float32).cuda()
+            hip.gemm_tn_batched(Pm.cuda(), Tn.cuda(), Zf, Mm, Nn, Kk, Nn, Kk, Kk, Bn, Mm * Nn, Mm * Kk, Nn * Kk)
+            assert (Zf.cpu() - ref).abs().max() < 1e-3 * max(1.0, float(ref.abs().max())), (Bn, Mm, Nn, Kk)
+            hip.gemm_tn_batched(Pm.cuda(), Tn.cuda(), Zf, Mm, Nn, Kk, Nn, Kk, Kk, Bn, Mm * Nn, Mm * Kk, Nn * Kk, accumulate=True)
+            assert (Zf.cpu() - 2 * ref).abs().max() < 2e-3 * max(1.0, float(ref.abs().max())), (Bn, Mm, Nn, Kk)
     # TN accumulate (f32 atomics, many row tiles, split over blocks): dW[h] += A[:, h]^T @ X[:, h]
     Mr = 1500
     Ar = torch.randn(Mr, Hh * 64, generator=g).to(dtype)
