@@ -92,6 +92,7 @@ class GeneralizedRCNN(nn.Module):
         # order (CDDMSL_SHARE_SOURCE_PASS=0 keeps it off there too).
         self.share_source_pass = False
         self._shared = None
+        self.defer_rpn_losses = True
 
     @property
     def device(self):
@@ -214,16 +215,24 @@ class GeneralizedRCNN(nn.Module):
         images, sizes = self.preprocess_image(batched_inputs, "image")
         gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]
         res4 = self.backbone.forward_nhwc(images, want_res5=False)["res4"]
-        proposals, proposal_losses = self.proposal_generator.forward_nhwc(sizes, res4, gts)
-        self._shared = None
-        if self.share_source_pass and self.use_clip_c4 and self.div_pixel:
-            self._shared = {"inputs": batched_inputs, "step": layers._STEP[0], "res4": res4, "sizes": sizes,
-                            "proposals": proposals, "counts": list(self.proposal_generator.last_counts)}
+        # The RPN losses wait for host-side anchor sampling: finish them after the box head is in the queue.  Only when the
+        # anchor and proposal samplers draw from separate generators (build_trainer seeds one each); with ONE shared stream
+        # -- the reference's global RNG, which the oracle parity tests mirror -- the draws keep the reference's order.
+        defer = self.defer_rpn_losses and self.proposal_generator.sample_generator is not self.roi_heads.sample_generator
+        proposals, rpn_losses = self.proposal_generator.forward_nhwc(sizes, res4, gts, defer_losses=True)
+        if not defer:
+            done = rpn_losses()
+            rpn_losses = lambda: done
         if self.use_clip_c4:    # C4 + CLIP weights: the head borrows the backbone's layer4 / attnpool (rcnn.py:606-612)
             _, detector_losses = self.roi_heads(ImageList(None, sizes), {"res4": to_nchw(res4)}, proposals, gts,
                                                 res5=self.backbone.layer4, attnpool=self.backbone.attnpool)
         else:                   # default setting (rcnn.py:613-614)
             _, detector_losses = self.roi_heads(ImageList(None, sizes), {"res4": to_nchw(res4)}, proposals, gts)
+        proposal_losses = rpn_losses()
+        self._shared = None
+        if self.share_source_pass and self.use_clip_c4 and self.div_pixel:
+            self._shared = {"inputs": batched_inputs, "step": layers._STEP[0], "res4": res4, "sizes": sizes,
+                            "proposals": proposals, "counts": list(self.proposal_generator.last_counts)}
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)

@@ -320,7 +320,10 @@ class RPN(nn.Module):
 
         return finish if defer else finish()
 
-    def forward_nhwc(self, image_sizes, res4, gt_instances=None):
+    def forward_nhwc(self, image_sizes, res4, gt_instances=None, defer_losses=False):
+        """``defer_losses``: return ``(proposals, losses_fn)``; the caller runs ``losses_fn()`` after it has enqueued the
+        box head, so the host half of the anchor sampling (16 x randperm(62 k) ~ 6 ms) runs under that device work instead
+        of stalling the queue.  The anchor and proposal samplers own separate generators, so the draw order is unchanged."""
         N, hf, wf, _ = res4.shape
         logits, deltas = self.rpn_head.forward_nhwc(res4)
         lg = logits.reshape(N, -1)                # (N, Hi*Wi*A)   rpn.py:456-460
@@ -336,9 +339,16 @@ class RPN(nn.Module):
             anchors = self.anchor_generator.grid(hf, wf)
             pending = self.label_anchors_begin(anchors, gt_instances)
         finish = self.predict_proposals(lg, dl, image_sizes, hf, wf, defer=True)
-        if pending is not None:
+
+        def losses_fn():
+            if pending is None:
+                return {}
             labels, matched = self.label_anchors_finish(*pending)
-            losses = self.losses(anchors, lg, labels, dl, matched)
+            return self.losses(anchors, lg, labels, dl, matched)
+
+        if defer_losses:
+            return finish(), losses_fn
+        losses = losses_fn()
         return finish(), losses
 
     def forward(self, images, features, gt_instances=None):

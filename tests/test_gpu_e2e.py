@@ -90,6 +90,37 @@ def test_step_losses_and_grads_match_oracle(kd, share, gemm256, monkeypatch):
     print("losses", got, "worst grad rel err", worst)
 
 
+def test_deferred_rpn_losses_give_the_same_step():
+    """With one generator per sampler (build_trainer's setup) the RPN's host-side anchor sampling and its losses are
+    finished after the box head has been enqueued (rcnn.py, rpn.py forward_nhwc defer_losses).  The draws of each stream
+    are the same either way, so losses and gradients must not change (f32; only the f32-atomic summation order differs)."""
+    from cddmsl_amd import synthetic
+    from cddmsl_amd.engine import SimpleTrainer
+    from cddmsl_amd.solver import build_optimizer
+    cfg = _cfg("f32")
+    batch = synthetic.make_batch(2, 160, 224, num_gt=3)
+    res = []
+    for defer in (True, False):
+        model, mapper, _, _ = _build(cfg, seed=5)
+        model.proposal_generator.sample_generator = torch.Generator().manual_seed(11)
+        model.roi_heads.sample_generator = torch.Generator().manual_seed(12)
+        model.region_generator = torch.Generator().manual_seed(13)
+        model.defer_rpn_losses = defer
+        tr = SimpleTrainer(model, iter([batch]), build_optimizer(cfg, model), cfg, clipcap_model=mapper, metrics_period=0)
+        tr.iter = 20000
+        tr.buckets.zero()
+        ld = tr.compute_losses(batch)
+        sum(ld.values()).backward()
+        res.append(({k: float(v) for k, v in ld.items()},
+                    {k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb) = res
+    assert set(la) == set(lb) and set(ga) == set(gb)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * max(float(gb[k].abs().max()), 1e-5), k
+
+
 @pytest.mark.parametrize("gemm256", ["1", "2"])
 def test_bf16_step_runs_and_is_close(gemm256, monkeypatch):
     """Throughput path (bf16 MFMA, fp32 accumulate): finite losses, loosely near the f32 oracle values (bf16 has
