@@ -25,7 +25,11 @@ __device__ __forceinline__ float bf2f(unsigned short u) {
   return __builtin_bit_cast(float, ((unsigned int)u) << 16);
 }
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+  // one v_cvt_pk_bf16_f32 (round to nearest even, the same conversion f2bf performs) instead of two converts + shift + or
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
