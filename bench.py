@@ -131,7 +131,7 @@ def main():
         gb = args.batch * world
         # dominant kernel = the single kernel with the most device time (k_conv_fwd256 on this workload); the C-ABI reports
         # which kernel each conv / GEMM entry point launched (cddmsl_last_kernel), so a profiler row is one kernel
-        gemm_rows = [k for k in ("k_conv_fwd256p", "k_conv_fwd256", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma") if k in prof]
+        gemm_rows = [k for k in ("k_conv_fwd256", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma") if k in prof]
         dom_name = max(gemm_rows, key=lambda k: prof[k]["ms"]) if gemm_rows else "k_conv_fwd256"
         dom = prof.get(dom_name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
         # HBM traffic per launch of that kernel from the PMC passes (tools/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE)

@@ -1591,21 +1591,6 @@ static inline int g_batch_peek() { return g_batch; }
 // no per-lane address arithmetic.  Filter-tap validity is a per-row bit mask (KH*KW <= 31 bits): an out-of-image tap or
 // an out-of-range row sets bit 31 of the lane's offset, which the range check turns into zeros written to LDS.
 // ------------------------------------------------------------------------------------------------
-// pointers re-read from the kernarg segment are generic; these casts keep the accesses global_load / global_store
-typedef const u32x4 __attribute__((address_space(1)))* GC4;
-typedef const float __attribute__((address_space(1)))* GCF;
-typedef u32x4 __attribute__((address_space(1)))* GU4;
-typedef f32x4 __attribute__((address_space(1)))* GF4;
-__device__ __forceinline__ int fresh_lane() {   // lane id the compiler cannot common up with (and keep live from) an earlier one
-  int l;
-  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-  return l;
-}
-__device__ __forceinline__ const char* uniform_ptr(const char* q) {      // a wave-uniform pointer the compiler cannot prove uniform
-  const unsigned long long v = (unsigned long long)q;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (const char*)(((unsigned long long)hi << 32) | lo);
-}
 __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, void* l) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, (int)soff, 0, 0);
 }
@@ -1919,439 +1904,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Persistent form of k_conv_fwd256: one block per CU walks a list of output tiles and the four staging streams (A0, A1,
-// B0, B1) run straight across tile boundaries -- the K-tile sequence of all the block's tiles is ONE pipeline, so the next
-// tile's first two K-tiles are already in LDS (or in flight) while a tile's epilogue runs, and there is no block launch /
-// prologue latency per tile.  That matters on the short-K wide-N layers (K = 512, N = 2048: 8 K-tiles per tile), where the
-// one-tile-per-block kernel spends as long outside its main loop as inside.
-//   * a stream that has staged the last K-tile of its tile re-derives its per-lane offsets / tap masks / buffer base for
-//     the block's next tile (stageA / stageB "wrap"); streams wrap at different phases, each keeps its own cursor;
-//   * the epilogue transposes through a private 4 KiB-per-wave region BEHIND the two staging buffers (LDS = 160 KiB), one
-//     32x32 accumulator block at a time, with no barrier; group 1 still runs one barrier behind group 0, so one group's
-//     epilogue overlaps the other group's last / first MFMA phase;
-//   * vmcnt retires in order and counts the epilogue's loads and stores too: the phase-3 wait (all but the 4 youngest)
-//     can only wait for more than it needs, never less.
-// Tile order: XCD x (blocks x, x+8, ...) owns a contiguous run of logical tiles and its blocks take them round-robin, so
-// the tiles in flight on one L2 share A row panels and the weight panel.
-// ------------------------------------------------------------------------------------------------
-template <typename T, bool TAPS>
-__global__ __launch_bounds__(512) void k_conv_fwd256p(ConvArgs p, FastDiv dtpb, FastDiv dntn, int total_tiles) {
-  __shared__ __attribute__((aligned(16))) u32x4 lds[(2 * 2 * 2 * 128 * KCH) + 2048];   // staging 128 KiB | epilogue 8 x 4 KiB
-  const int wvu = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wvu >> 2, wc = wvu & 3;
-  // The main loop runs at the register limit (128 accumulators + 96 fragment registers): everything lane-derived that only
-  // the once-per-tile paths need is recomputed there from a fresh lane id instead of being carried through the loop.
-  const int nkt = p.Kc >> 3;
-  const int tpt = p.cpp >> 3;                   // K-tiles per filter tap
-
-  // ---- this block's tiles: tfirst, tfirst + tstep, ... (nmine of them)
-  int tfirst, tstep, nmine;
-  {
-    const int G = gridDim.x, xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-    const int nbx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
-    const int q = total_tiles >> 3, rem = total_tiles & 7;
-    const int cnt = q + (xcd < rem ? 1 : 0);
-    tfirst = xcd * q + min(xcd, rem) + l;
-    tstep = nbx;
-    nmine = l < cnt ? (cnt - l + nbx - 1) / nbx : 0;
-  }
-  if (nmine == 0) return;
-  const int gk = nmine * nkt;                   // K-tiles of the whole pipeline
-  auto decode = [&](int it, int& b, int& m0, int& n0) {      // (multiply-high divisions by tiles-per-batch and column tiles: scalar ALU)
-    const unsigned tid = (unsigned)(tfirst + it * tstep);
-    const unsigned bq = fdiv(tid, dtpb), r = tid - bq * dtpb.d;
-    const unsigned tm = fdiv(r, dntn);
-    b = (int)bq; m0 = (int)tm * 256; n0 = (int)(r - tm * dntn.d) * 256;
-  };
-
-  // Arguments that only the once-per-tile paths need (stream wrap, epilogue) are re-read from the kernarg segment there
-  // (scalar loads through a constant-address-space pointer made opaque, so they are not hoisted) instead of living in
-  // SGPRs across the main loop.
-  typedef const ConvArgs __attribute__((address_space(4))) KArgs;
-  auto args = [&]() -> KArgs* {
-    KArgs* ka = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    return ka;
-  };
-  struct RowGeo { unsigned wmul, wshr, hmul, hshr; int Wo, Ho, stride, pad, Hi, Wi, xrs; };
-  auto rowoff = [&](const RowGeo& q, int m, int& iy0, int& ix0) {
-    const unsigned tq = (__umulhi((unsigned)m, q.wmul) + (unsigned)m) >> q.wshr, ox = m - tq * q.Wo;
-    const unsigned img = (__umulhi(tq, q.hmul) + tq) >> q.hshr, oy = tq - img * q.Ho;
-    iy0 = (int)oy * q.stride - q.pad; ix0 = (int)ox * q.stride - q.pad;
-    return (((long)img * q.Hi + iy0) * q.Wi + ix0) * q.xrs * 16;
-  };
-  // ---- staging streams.  A half h, piece i -> tile row i*128 + h*64 + (t>>3);  B half j, piece i -> tile col
-  // (2i + (t>>8))*64 + j*32 + ((t>>3)&31).  Per-lane offsets are constant over a tile's K loop, the running K / tap position
-  // is the wave-uniform soffset; bit 31 of a lane's offset (row outside M, tap outside the image) makes the load write zeros.
-  const char* baseA[2] = {nullptr, nullptr};
-  const char* baseB = nullptr;                  // B0 and B1 are always staged back to back: one base
-  unsigned va[2][2], vinv[2][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { va[h][i] = 0; vinv[h][i] = 0; }
-  unsigned vb00;                                // B half j, piece i: + (i*128 + j*32) rows (uniform)
-  {
-    const int t = wvu * 64 + fresh_lane();
-    vb00 = (unsigned)(((t >> 8) * 64 + ((t >> 3) & 31)) * p.wrs + ((t & 7) ^ ((t >> 4) & 7))) * 16;
-  }
-  const unsigned wrow32 = (unsigned)p.wrs * 16 * 32;
-  const int step_col = (p.xrs - (p.cpp - KCH)) * 16;                               // next tap in the same filter row
-  const int step_row = ((p.Wi - (p.KW - 1)) * p.xrs - (p.cpp - KCH)) * 16;         // first tap of the next filter row
-  int left[2] = {tpt, tpt}, tap[2] = {0, 0}, kxs[2] = {0, 0};
-  unsigned soa[2] = {0, 0}, sob = 0;
-
-  char* const L = (char*)lds;
-  // A stream h moves on to the block's tile number `it` (called from the once-per-tile path of the main loop, ahead of the
-  // stream's first stage call for that tile -- the stage calls themselves carry no tile logic)
-  auto wrapA = [&](auto H, int it, KArgs* ka) {
-    constexpr int h = decltype(H)::value;
-    RowGeo q;
-    q.wmul = ka->dWo.mul; q.wshr = ka->dWo.shr; q.hmul = ka->dHo.mul; q.hshr = ka->dHo.shr;
-    q.Wo = ka->Wo; q.Ho = ka->Ho; q.stride = ka->stride; q.pad = ka->pad; q.Hi = ka->Hi; q.Wi = ka->Wi; q.xrs = ka->xrs;
-    const int aM = ka->M, aKH = ka->KH, aKW = ka->KW;
-    const int t = wvu * 64 + fresh_lane();
-    const int cl = (t & 7) ^ ((t >> 4) & 7);    // logical K chunk of this lane's LDS slot (slot ^ ((row>>1)&7))
-    int b, m0, n0, iyb, ixb;
-    decode(it, b, m0, n0);
-    const long base_a = rowoff(q, m0, iyb, ixb);   // rows of one tile ascend from here (2*pad <= K-1, checked by the host)
-    baseA[h] = uniform_ptr(ka->x + (long)b * ka->bx + base_a);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + i * 128 + h * 64 + (t >> 3);
-      const bool vm = m < aM;
-      int iy0, ix0;
-      const long ro = rowoff(q, vm ? m : m0, iy0, ix0);
-      unsigned v = (unsigned)(ro - base_a) + cl * 16, inv = 0;
-      if (TAPS) {
-        // valid taps: kx in [xlo, xhi) as a bit run, repeated for every valid filter row (KH*KW <= 31 bits)
-        const int xlo = max(0, -ix0), xhi = min(aKW, q.Wi - ix0), ylo = max(0, -iy0), yhi = min(aKH, q.Hi - iy0);
-        const unsigned xm = (vm && xhi > xlo) ? ((1u << xhi) - 1u) & ~((1u << xlo) - 1u) : 0u;
-        unsigned ok = 0;
-        for (int ky = 0; ky < aKH; ++ky) ok |= (ky >= ylo && ky < yhi) ? xm << (ky * aKW) : 0u;
-        inv = ~ok;
-      } else if (!vm) v |= 0x80000000u;
-      va[h][i] = v; vinv[h][i] = inv;
-    }
-    soa[h] = 0; left[h] = tpt; tap[h] = 0; kxs[h] = 0;
-  };
-  auto wrapB = [&](int it, KArgs* ka) {
-    int b, m0, n0;
-    decode(it, b, m0, n0);
-    baseB = uniform_ptr(ka->w + (long)b * ka->bw + (long)n0 * ka->wrs * 16);
-    sob = 0;
-  };
-  auto stageA = [&](auto H, int buf) {
-    constexpr int h = decltype(H)::value;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)baseA[h], 0, 0x7fffffff, 0x00020000);
-    char* dst = L + (buf << 16) + (h << 14) + wvu * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      unsigned v = va[h][i];
-      if (TAPS) v |= __builtin_amdgcn_ubfe(vinv[h][i], (unsigned)tap[h], 1u) << 31;
-      blds16(rsrc, v, soa[h], dst + i * 8192);
-    }
-    if (TAPS) {
-      int step = KCH * 16;
-      if (--left[h] == 0) {
-        left[h] = tpt; ++tap[h];
-        if (++kxs[h] == p.KW) { kxs[h] = 0; step = step_row; } else step = step_col;
-      }
-      soa[h] += step;
-    } else soa[h] += KCH * 16;
-  };
-  auto stageB = [&](auto J, int buf) {
-    constexpr int j = decltype(J)::value;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)baseB, 0, 0x7fffffff, 0x00020000);
-    char* dst = L + (buf << 16) + (1 << 15) + (j << 14) + wvu * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) blds16(rsrc, vb00, sob + (4 * i + j) * wrow32, dst + i * 8192);
-    if (j == 1) sob += KCH * 16;
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  // ---- fragment reads: per-lane byte addresses per k-step, buffer bit (1<<16) toggled by XOR; half / row-tile offsets are immediates
-  unsigned ada[4], adb[4];
-  {
-    const int lane = fresh_lane();
-    const int r32 = lane & 31, hh = lane >> 5, sw = (r32 >> 1) & 7;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      ada[ks] = (unsigned)(((wr * 64 + r32) * KCH + ((2 * ks + hh) ^ sw)) * 16);
-      adb[ks] = (unsigned)(((wc * 32 + r32) * KCH + ((2 * ks + hh) ^ sw)) * 16 + (1 << 15));
-    }
-  }
-  u32x4 fa0[2][4], fa1[2][4], fb0[4], fb1[4];
-  auto readA = [&](auto I, u32x4 (*fa)[4]) {
-    constexpr int i = decltype(I)::value;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[rt][ks] = *(const u32x4*)(L + ada[ks] + ((i << 14) + rt * 32 * KCH * 16));
-  };
-  auto readB = [&](auto J, u32x4* fb) {
-    constexpr int j = decltype(J)::value;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) fb[ks] = *(const u32x4*)(L + adb[ks] + (j << 14));
-  };
-  auto flipA = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) ada[ks] ^= 1u << 16;
-  };
-  auto flipB = [&]() {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) adb[ks] ^= 1u << 16;
-  };
-#define CDDMSL_MMA_QUAD(I, J, FA, FB)                                               \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
-    Mma<T>::step(acc[2 * (I)][J], FA[0][ks], FB[ks]);                               \
-    Mma<T>::step(acc[2 * (I) + 1][J], FA[1][ks], FB[ks]);                           \
-  }
-#define CDDMSL_PHASE_SYNC_IN()                                                      \
-  __builtin_amdgcn_sched_barrier(0);                                                \
-  __builtin_amdgcn_s_barrier();                                                     \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
-  __builtin_amdgcn_sched_barrier(0);                                                \
-  __builtin_amdgcn_s_setprio(1);
-#define CDDMSL_PHASE_SYNC_OUT(I, J)                                                 \
-  asm volatile("" : "+v"(acc[2 * (I)][J]), "+v"(acc[2 * (I) + 1][J]));   /* the MFMAs above cannot sink below the barrier */ \
-  __builtin_amdgcn_s_setprio(0);                                                    \
-  __builtin_amdgcn_sched_barrier(0);                                                \
-  __builtin_amdgcn_s_barrier();                                                     \
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- epilogue of one tile: 8 accumulator blocks (32 rows x 32 cols f32) through this wave's 4 KiB region; DS ops of
-  // one wave execute in order, so no barrier.  Lanes then own 8 consecutive columns of a row: 16-byte residual / mask
-  // loads and y stores, all buffer-addressed -- rows past M fall outside num_records (loads give 0, stores are dropped)
-  // and an absent residual / mask is a zero-sized buffer -- so the whole epilogue is straight-line code: the compiler's
-  // vmcnt waits for the residual registers (requested two blocks ahead) are exact counts, and never wait for the stores
-  // just issued or for the next tile's DMA behind them.  FrozenBN scale / bias are applied in the accumulator layout
-  // (a lane's column is fixed there): 2 + 2 registers, requested one K-tile ahead (load_affine).
-  constexpr int ES = Mma<T>::ES;
-  float sc2[2] = {1.f, 1.f}, bi2[2] = {0.f, 0.f};
-  auto load_affine = [&](int n0, KArgs* ka) {
-    const float* scale = ka->scale; const float* bias = ka->bias;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr((const char*)scale), 0, scale ? 0x7fffffff : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr((const char*)bias), 0, bias ? 0x7fffffff : 0, 0x00020000);
-    const unsigned vo = (unsigned)(n0 + wc * 64 + (fresh_lane() & 31)) * 4;
-#pragma unroll
-    for (int b2 = 0; b2 < 2; ++b2) {              // (no arithmetic on the results here: that would wait for them at once)
-      sc2[b2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, b2 * 128, 0));
-      bi2[b2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, vo, b2 * 128, 0));
-    }
-  };
-  auto epilogue = [&](int bb, int m0, int n0) {
-    KArgs* ka = args();
-    const int aM = ka->M, ldy = ka->ldy, ldr = ka->ldr, ldm = ka->ldm;
-    const bool f32out = ES == 4 || ka->out_f32 != 0;
-    const int eso = f32out ? 4 : 2;
-    const char* res = ka->residual; const char* msk = ka->relu_mask;
-    const float relu_floor = ka->relu ? 0.f : -__builtin_inff();
-    const float one = ka->scale ? 0.f : 1.f;    // an absent scale buffer reads as 0
-    const long rows = aM - m0;
-    auto mk = [&](const char* base, long ld, int es) {
-      long bytes = rows * ld * es;
-      if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
-      return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(base + (long)m0 * ld * es), 0, base ? (int)bytes : 0, 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t ry = mk(ka->y + (long)bb * ka->by, ldy, eso), rres = mk(res, ldr, ES), rmsk = mk(msk, ldm, ES);
-    float* const ep = (float*)(L + 131072) + wvu * 1024;
-    const int lane = fresh_lane();
-    const int r32 = lane & 31, hh = lane >> 5;
-    const int cg = lane & 3, rr = lane >> 2;    // 16 rows x 4 column groups per half block
-    const int col = n0 + wc * 64 + cg * 8;
-    const unsigned vy = (unsigned)(((wr * 128 + rr) * ldy + col) * eso);
-    const unsigned vr = (unsigned)(((wr * 128 + rr) * ldr + col) * ES), vm = (unsigned)(((wr * 128 + rr) * ldm + col) * ES);
-    u32x4 rresb[2][2][ES / 2], rmskb[2][2][ES / 2];
-    auto fetch = [&](int idx, u32x4 (*rr_)[ES / 2], u32x4 (*rm_)[ES / 2]) {
-      const int a = idx & 3, b2 = idx >> 2;
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int q = 0; q < ES / 2; ++q) {
-          rr_[s][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, ((a * 32 + 16 * s) * ldr + b2 * 32) * ES + q * 16, 0);
-          rm_[s][q] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, ((a * 32 + 16 * s) * ldm + b2 * 32) * ES + q * 16, 0);
-        }
-    };
-    fetch(0, rresb[0], rmskb[0]);
-    fetch(1, rresb[1], rmskb[1]);
-#pragma unroll
-    for (int idx = 0; idx < 8; ++idx) {
-      const int a = idx & 3, b2 = idx >> 2;
-      u32x4 (*rres_)[ES / 2] = rresb[idx & 1];
-      u32x4 (*rmsk_)[ES / 2] = rmskb[idx & 1];
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = (g & 3) + 8 * (g >> 2) + 4 * hh;
-        ep[row * 32 + ((((r32 >> 3) ^ ((row >> 1) & 3)) << 3) | (r32 & 7))] = acc[a][b2][g] * (sc2[b2] + one) + bi2[b2];
-        acc[a][b2][g] = 0.f;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int row = rr + 16 * s;
-        const f32x4* src = (const f32x4*)(ep + row * 32 + ((cg ^ ((row >> 1) & 3)) << 3));
-        const f32x4 v0 = src[0], v1 = src[1];
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (res) {
-          if (ES == 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(rres_[s][0][j] & 0xffff); v[2 * j + 1] += bf2f(rres_[s][0][j] >> 16); }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              v[j] += __builtin_bit_cast(f32x4, rres_[s][0])[j]; v[4 + j] += __builtin_bit_cast(f32x4, rres_[s][ES / 2 - 1])[j];
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "s"(relu_floor));   // (fmaxf adds a canonicalising op per element)
-        if (msk) {
-          float mv[8];
-          if (ES == 2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { mv[2 * j] = bf2f(rmsk_[s][0][j] & 0xffff); mv[2 * j + 1] = bf2f(rmsk_[s][0][j] >> 16); }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              mv[j] = __builtin_bit_cast(f32x4, rmsk_[s][0])[j]; mv[4 + j] = __builtin_bit_cast(f32x4, rmsk_[s][ES / 2 - 1])[j];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
-        }
-        const unsigned so = (unsigned)(((a * 32 + 16 * s) * ldy + b2 * 32) * eso);
-        if (f32out) {
-          const u32x4 o0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
-          const u32x4 o1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
-          __builtin_amdgcn_raw_buffer_store_b128(o0, ry, vy, so, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(o1, ry, vy, so + 16, 0);
-        } else {
-          const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-          __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, 0);
-        }
-      }
-      if (idx + 2 < 8) fetch(idx + 2, rresb[idx & 1], rmskb[idx & 1]);
-    }
-  };
-
-  // ---- prologue: K-tile 0 complete, K-tile 1 without its A1 half (staged by phase 1 of K-tile 0); A0 of K-tile 0 is read ahead
-  {
-    KArgs* ka = args();
-    wrapA(I0{}, 0, ka); wrapA(I1{}, 0, ka); wrapB(0, ka);
-  }
-  stageA(I0{}, 0); stageA(I1{}, 0); stageB(I0{}, 0); stageB(I1{}, 0);
-  if (gk > 1) {
-    if (nkt == 1) { KArgs* ka = args(); wrapA(I0{}, 1, ka); wrapB(1, ka); }  // one K-tile per tile: K-tile 1 is the next tile
-    stageA(I0{}, 1); stageB(I0{}, 1); stageB(I1{}, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  readA(I0{}, fa0);
-  if (wr == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
-  __builtin_amdgcn_sched_barrier(0);
-
-  int itC = 0, ktC = 0;                          // tile being accumulated, K-tiles of it done
-  for (int g = 0; g < gk; ++g) {
-    const int d = g & 1;
-    const bool more1 = g + 1 < gk, more2 = g + 2 < gk;
-    if (__builtin_expect(ktC + 2 >= nkt, 0)) {   // once-per-tile work, all of it on this one cold branch
-      KArgs* ka = args();                        // (one pointer: the kernarg re-reads of this pass share one scalar-load latency)
-      if (ktC + 1 == nkt) {                      // last K-tile of the tile: request its scale / bias now;
-        int bb, m0, n0;                          // A1 (phase 1 stages K-tile g+1) enters the next tile
-        decode(itC, bb, m0, n0);
-        load_affine(n0, ka);
-        if (more1) wrapA(I1{}, itC + 1, ka);
-      }
-      // A0, B0, B1 stage K-tile g+2 in phases 2-4: the first K-tile of the next tile (of the one after it if nkt == 1)
-      if (more2 && (nkt == 1 || ktC + 2 == nkt)) {
-        const int nt = nkt == 1 ? itC + 2 : itC + 1;
-        wrapA(I0{}, nt, ka); wrapB(nt, ka);
-      }
-    }
-    // phase 1
-    readB(I0{}, fb0);
-    if (more1) stageA(I1{}, d ^ 1);
-    CDDMSL_PHASE_SYNC_IN();
-    CDDMSL_MMA_QUAD(0, 0, fa0, fb0);
-    CDDMSL_PHASE_SYNC_OUT(0, 0);
-    // phase 2
-    readB(I1{}, fb1);
-    flipB();
-    if (more2) stageA(I0{}, d);
-    CDDMSL_PHASE_SYNC_IN();
-    CDDMSL_MMA_QUAD(0, 1, fa0, fb1);
-    CDDMSL_PHASE_SYNC_OUT(0, 1);
-    // phase 3: the wait retires everything but the two youngest half-tiles, i.e. all of K-tile g+1 (other buffer)
-    readA(I1{}, fa1);
-    flipA();
-    if (more2) {
-      stageB(I0{}, d);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    CDDMSL_PHASE_SYNC_IN();
-    CDDMSL_MMA_QUAD(1, 1, fa1, fb1);
-    CDDMSL_PHASE_SYNC_OUT(1, 1);
-    // phase 4 (the A0 read-ahead of a tile's last K-tile is issued after the epilogue instead: 32 registers less across it)
-    const bool tile_done = ktC + 1 == nkt;
-    if (!tile_done) readA(I0{}, fa0);              // (the pipeline's last K-tile is a tile's last one)
-    if (more2) stageB(I1{}, d);
-    CDDMSL_PHASE_SYNC_IN();
-    CDDMSL_MMA_QUAD(1, 0, fa1, fb0);
-    CDDMSL_PHASE_SYNC_OUT(1, 0);
-    ++ktC;
-    if (__builtin_expect(tile_done, 0)) {        // tile complete: write it out (the pipeline already holds the next tile's head)
-      // Both groups run their epilogues together: group 0 waits here for group 1's last MFMA phase, and group 1 drops
-      // one barrier behind again afterwards -- otherwise each group would sit at a barrier through the other's epilogue.
-      if (wr == 0) __builtin_amdgcn_s_barrier();
-      int bb, m0, n0;
-      decode(itC, bb, m0, n0);
-      epilogue(bb, m0, n0);
-      ktC = 0; ++itC;
-      __builtin_amdgcn_sched_barrier(0);
-      // K-tile g+1 is complete in LDS since phase 3.  Its A0 half is restaged in phase 2 of the next iteration, which
-      // the leading group enters right behind the barrier this wave arrives at next: retire the reads before arriving.
-      // (Unconditional -- after the pipeline's last K-tile it reads stale LDS that nobody uses -- so that the old
-      // fragment is dead across the epilogue on every path.)
-      readA(I0{}, fa0);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa0[0][0]), "+v"(fa0[0][1]), "+v"(fa0[0][2]), "+v"(fa0[0][3]),
-                   "+v"(fa0[1][0]), "+v"(fa0[1][1]), "+v"(fa0[1][2]), "+v"(fa0[1][3]) :: "memory");
-      if (wr == 1 && more1) __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#undef CDDMSL_MMA_QUAD
-#undef CDDMSL_PHASE_SYNC_IN
-#undef CDDMSL_PHASE_SYNC_OUT
-}
-
 // Shapes the 256x256 kernel takes: whole 256-column tiles, K-tiles inside one filter tap, vector epilogue, <= 32 taps,
 // and enough tiles to fill the chip.  Environment CDDMSL_GEMM256 (read per launch, so one process can A/B): 0 = always the
 // 128x128 kernel, 2 = the 256x256 kernel wherever it is legal, unset/1 = the heuristic below.
-static int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
-  }
-  return n;
-}
-
 static bool use_gemm256(const ConvArgs& a) {
   const char* e = getenv("CDDMSL_GEMM256");
   const int mode = e ? atoi(e) : 1;
@@ -2384,23 +1939,7 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   if (use_gemm256(a)) {
     grid = (long)(a.Cout / 256) * ((a.M + 255) / 256);
     g_last_kernel = 3;
-    // Persistent form (k_conv_fwd256p) where a tile has at least 8 K-tiles: below that the one-tile-per-block kernel's
-    // 4-pass epilogue wins (measured).  CDDMSL_PERSIST: 0 = never, 2 = wherever the 256x256 kernel runs (tests).
-    const char* pe = getenv("CDDMSL_PERSIST");
-    const int pmode = pe ? atoi(pe) : 1;
-    const bool plain = !a.residual && !a.relu_mask;
-    const bool one_by_one = a.KH == 1 && a.KW == 1 && a.pad == 0;
-    if (pmode == 2 || (pmode == 1 && (a.Kc >> 3) >= 8) || (pmode == 3 && (a.Kc >> 3) >= 8 && plain) ||
-        (pmode == 4 && (a.Kc >> 3) >= 8 && plain && one_by_one)) {
-      g_last_kernel = 10;
-      const long total = grid * g_batch;
-      if (total > 0x7fffffffL) return CDDMSL_ERR_ARG;
-      const unsigned nb = (unsigned)(total < num_cus() ? total : num_cus());
-      if (a.KH == 1 && a.KW == 1 && a.pad == 0)
-        hipLaunchKernelGGL((k_conv_fwd256p<T, false>), dim3(nb), dim3(512), 0, st, a, make_fastdiv((unsigned)grid), make_fastdiv((unsigned)(a.Cout >> 8)), (int)total);
-      else
-        hipLaunchKernelGGL((k_conv_fwd256p<T, true>), dim3(nb), dim3(512), 0, st, a, make_fastdiv((unsigned)grid), make_fastdiv((unsigned)(a.Cout >> 8)), (int)total);
-    } else if (a.KH == 1 && a.KW == 1 && a.pad == 0)
+    if (a.KH == 1 && a.KW == 1 && a.pad == 0)
       hipLaunchKernelGGL((k_conv_fwd256<T, false>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
     else
       hipLaunchKernelGGL((k_conv_fwd256<T, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);

@@ -49,7 +49,7 @@ int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, int M, int N
                            long sb, long so, int mode, int dtype, void* stream);
 /* diagnostic: the kernel the calling thread's last conv / GEMM entry point launched -- 1 k_conv_fwd (128x128 LDS-DMA),
  * 2 k_conv_fwd_reg (fused avg-pool loader), 3 k_conv_fwd256 (256x256 ping-pong), 4 k_conv_wgrad, 5 k_conv_wgrad_dma,
- * 6 k_wgrad256, 7 k_gemm_tn_stream, 8 k_conv3x3_small (few-channel 3x3 layers: the CLIP stem), 9 k_gemm_tn_small, 10 k_conv_fwd256p (persistent 256x256).  bench.py uses it to attribute HIP-event times to kernels. */
+ * 6 k_wgrad256, 7 k_gemm_tn_stream, 8 k_conv3x3_small (few-channel 3x3 layers: the CLIP stem), 9 k_gemm_tn_small.  bench.py uses it to attribute HIP-event times to kernels. */
 int cddmsl_last_kernel(void);
 /* f32 master -> `dtype` forward weights and flipped/transposed dgrad weights scaled by the FrozenBN scale */
 int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int Cout, int KH, int KW, int Cin,

@@ -215,78 +215,6 @@ def test_conv_fwd_256_tile_kernel(case, dtype, tol, monkeypatch):
         assert (a - b).abs().max() <= tol * a.abs().max()
 
 
-PERSIST_CASES = [
-    # N, H, W, Cin, Cout, K, pad        more than 256 output tiles: blocks of the persistent kernel walk 2-3 tiles each
-    (4, 128, 140, 64, 512, 1, 0),       # bf16: ONE K-tile per tile (every stream enters a new tile at every step); 560 tiles
-    (4, 128, 140, 128, 512, 1, 0),      # bf16: two K-tiles per tile
-    (4, 128, 140, 64, 256, 3, 1),       # 9 taps, 280 tiles (ragged: 24 blocks take a second tile), tap masks re-derived per tile
-    (3, 150, 160, 192, 256, 1, 0),      # odd K-tile count (3 in bf16), 282 tiles, ragged last row tile (M = 72000)
-]
-
-
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("case", PERSIST_CASES)
-def test_conv_fwd_256_persistent_kernel(case, dtype, tol, monkeypatch):
-    """k_conv_fwd256p (one block per CU walking a tile list, staging streams running across tile boundaries), forced with
-    CDDMSL_PERSIST=2, against ATen fp32, the one-tile-per-block 256x256 kernel and the 128x128 kernel; residual + ReLU
-    forward and the masked (dgrad) form, bf16 and f32 output."""
-    from cddmsl_amd import hip
-    N, H, W, Cin, Cout, K, p = case
-    x = _rand((N, Cin, H, W), 51).to(dtype).float()
-    w = (_rand((Cout, Cin, K, K), 52) * (Cin * K * K) ** -0.5).to(dtype).float()
-    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(53)) + 0.5
-    bias = _rand((Cout,), 54, 0.1)
-    conv = F.conv2d(x, w, padding=p)
-    res = _rand(tuple(conv.shape), 55).to(dtype).float()
-    y_ref = F.relu(conv * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res)
-    m_ref = conv * (res > 0)
-    dev = "cuda"
-    xg, rg = _nhwc(x).to(dev, dtype), _nhwc(res).to(dev, dtype)
-    wf, _ = hip.weight_prep(w.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), dtype)
-    out = {}
-    for name, g256, persist, kid in (("128", "0", "0", 1), ("256", "2", "0", 3), ("256p", "2", "2", 10)):
-        monkeypatch.setenv("CDDMSL_GEMM256", g256)
-        monkeypatch.setenv("CDDMSL_PERSIST", persist)
-        y = hip.conv_fwd(xg, wf, scale.to(dev), bias.to(dev), rg, relu=True, stride=1, pad=p)
-        assert hip._L().cddmsl_last_kernel() == kid, name
-        msk = hip.conv_fwd(xg, wf, relu_mask=rg, stride=1, pad=p)
-        yf = hip.conv_fwd(xg, wf, None, bias.to(dev), None, stride=1, pad=p, out_f32=True)
-        torch.cuda.synchronize()
-        out[name] = (y.float().cpu(), msk.float().cpu(), yf.cpu())
-    assert (out["256p"][0].permute(0, 3, 1, 2) - y_ref).abs().max() < tol * y_ref.abs().max()
-    assert (out["256p"][1].permute(0, 3, 1, 2) - m_ref).abs().max() < tol * m_ref.abs().max()
-    f_ref = conv + bias.view(1, -1, 1, 1)
-    assert (out["256p"][2].permute(0, 3, 1, 2) - f_ref).abs().max() < tol * f_ref.abs().max()
-    for a, b in zip(out["256"], out["256p"]):       # same staging, same accumulation order, same epilogue arithmetic
-        assert torch.equal(a, b)
-    for a, b in zip(out["128"], out["256p"]):
-        assert (a - b).abs().max() <= tol * a.abs().max()
-
-
-def test_batched_nt_on_the_persistent_kernel(monkeypatch):
-    """gemm_nt_batched (the attention pool's per-head products) with the batch axis folded into the persistent kernel's
-    tile list: 3 batches x (2 x 2) tiles, strided operands, f32 and bf16 outputs."""
-    from cddmsl_amd import hip
-    g = torch.Generator().manual_seed(61)
-    M, Hh, Kd, N = 300, 3, 512, 512
-    A = torch.randn(M, Hh * Kd, generator=g).bfloat16()
-    Wt = (torch.randn(Hh * N, Kd, generator=g) * Kd ** -0.5).bfloat16()
-    ref = torch.cat([A.float()[:, h * Kd:(h + 1) * Kd] @ Wt.float()[h * N:(h + 1) * N].t() for h in range(Hh)], dim=1)
-    outs = {}
-    for persist, kid in (("0", 3), ("2", 10)):
-        monkeypatch.setenv("CDDMSL_GEMM256", "2")
-        monkeypatch.setenv("CDDMSL_PERSIST", persist)
-        C = torch.zeros(M, Hh * N, dtype=torch.float32).cuda()
-        hip.gemm_nt_batched(A.cuda(), Wt.cuda(), C, M, N, Kd, Hh * Kd, Kd, Hh * N, Hh, Kd, N * Kd, N)
-        assert hip._L().cddmsl_last_kernel() == kid
-        Cb = torch.zeros(M, Hh * N, dtype=torch.bfloat16).cuda()
-        hip.gemm_nt_batched(A.cuda(), Wt.cuda(), Cb, M, N, Kd, Hh * Kd, Kd, Hh * N, Hh, Kd, N * Kd, N)
-        outs[persist] = (C.cpu(), Cb.float().cpu())
-    assert (outs["2"][0] - ref).abs().max() < 2e-2 * ref.abs().max()
-    assert (outs["2"][1] - ref).abs().max() < 2e-2 * ref.abs().max()
-    assert torch.equal(outs["0"][0], outs["2"][0]) and torch.equal(outs["0"][1], outs["2"][1])
-
-
 CASES_W256 = [
     # N, H, W, Cin, Cout, K, pad     (Cout % 256 == 0, KH*KW*Cin % 256 == 0, Cin % 64 == 0)
     (3, 14, 14, 256, 256, 3, 1),     # M = 588: ragged last reduction tile, 9 taps
