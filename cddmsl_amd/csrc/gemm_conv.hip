@@ -1810,7 +1810,12 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
 #undef CDDMSL_STAMP
 
   // ---- epilogue: per-wave LDS transpose (32 rows x 64 cols f32 per pass, private 8 KiB region; DS ops of one wave
-  // execute in order, so no barrier is needed), 16-byte vector loads/stores of residual / mask / y.
+  // execute in order, so no barrier is needed); a lane then owns 8 consecutive columns of a row: 16-byte residual / mask
+  // loads and y stores.  All of them are buffer-addressed -- rows past M fall outside num_records (loads give 0, stores
+  // are dropped), an absent residual / mask is a zero-sized buffer, per-lane offsets are computed once and the row / pass
+  // position is the wave-uniform soffset -- so the passes are straight-line code without per-row exec masks, zero fills or
+  // 64-bit address arithmetic (together ~half of the old epilogue's vector instructions).
+  constexpr int ES = Mma<T>::ES;
   float* ep = (float*)lds + wvu * 2048;
   const int cg = lane & 7, rr = lane >> 3;
   const int n = n0 + wc * 64 + cg * 8;
@@ -1820,84 +1825,93 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     sc[j] = p.scale ? p.scale[n + j] : 1.f;
     bi[j] = p.bias ? p.bias[n + j] : 0.f;
   }
-  constexpr int ES = Mma<T>::ES;
+  const bool f32out = ES == 4 || p.out_f32 != 0;
+  const int eso = f32out ? 4 : 2;
+  const float relu_floor = p.relu ? 0.f : -__builtin_inff();
+  const long rows = p.M - m0;
+  auto mk = [&](const char* base, long ld, int es) {
+    long bytes = rows * ld * es;
+    if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)m0 * ld * es), 0, base ? (int)bytes : 0, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t ry = mk(p.y, p.ldy, eso), rres = mk(p.residual, p.ldr, ES), rmsk = mk(p.relu_mask, p.ldm, ES);
+  const unsigned vy = (unsigned)(((wr * 128 + rr) * p.ldy + n) * eso);
+  const unsigned vr = (unsigned)(((wr * 128 + rr) * p.ldr + n) * ES), vm = (unsigned)(((wr * 128 + rr) * p.ldm + n) * ES);
   // bf16: residual / mask rows are fetched TWO passes ahead (two register sets, static indices): with one block per CU
-  // nothing else hides their HBM latency; passes 0 and 1 are requested together before any transpose starts.  The f32
-  // parity instantiation (twice the registers per row) fetches one pass ahead of its use only.
+  // nothing else hides their HBM latency.  The f32 parity instantiation (twice the registers per row) one pass ahead.
   constexpr int DEPTH = ES == 2 ? 2 : 1;
+  // transposition writes: the swizzled chunk (col>>3) ^ (row&7) splits into a lane part ((r32>>3) ^ (hh<<2)) XOR a
+  // compile-time part ((b<<2) ^ (g&3)): eight per-lane base addresses, the row of a register is an immediate offset
+  char* wbase[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    wbase[c] = (char*)ep + (hh * 4 * 64 + ((((r32 >> 3) ^ (hh << 2)) ^ c) << 3) + (r32 & 7)) * 4;
   u32x4 rresb[DEPTH][4][ES / 2], rmskb[DEPTH][4][ES / 2];
-  auto fetch = [&](int a, u32x4 (*rres)[ES / 2], u32x4 (*rmsk)[ES / 2]) {
-    const int mb = m0 + wr * 128 + a * 32;
+  auto fetch = [&](int a, u32x4 (*rres_)[ES / 2], u32x4 (*rmsk_)[ES / 2]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mb + rr + 8 * i;
-      const bool ok = m < p.M;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int q = 0; q < ES / 2; ++q) {
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        rres[i][q] = (ok && p.residual) ? ((const u32x4*)(p.residual + ((long)m * p.ldr + n) * ES))[q] : z;
-        rmsk[i][q] = (ok && p.relu_mask) ? ((const u32x4*)(p.relu_mask + ((long)m * p.ldm + n) * ES))[q] : z;
+      for (int q = 0; q < ES / 2; ++q) {       // (an absent operand is not requested at all: even a zero-sized buffer returns its zeros through the vector memory path)
+        if (p.residual) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * i) * p.ldr * ES + q * 16, 0);
+        if (p.relu_mask) rmsk_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, (a * 32 + 8 * i) * p.ldm * ES + q * 16, 0);
       }
-    }
   };
   if (DEPTH == 2) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const int mb = m0 + wr * 128 + a * 32;
     if (DEPTH == 1) fetch(a, rresb[0], rmskb[0]);
-    u32x4 (*rres)[ES / 2] = rresb[a % DEPTH];
-    u32x4 (*rmsk)[ES / 2] = rmskb[a % DEPTH];
+    u32x4 (*rres_)[ES / 2] = rresb[a % DEPTH];
+    u32x4 (*rmsk_)[ES / 2] = rmskb[a % DEPTH];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = (g & 3) + 8 * (g >> 2) + 4 * hh, col = b * 32 + r32;
-        ep[row * 64 + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7))] = acc[a][b][g];
-      }
+      for (int g = 0; g < 16; ++g)                  // element (row rg + 4hh, col 32b + r32) -> ep[row*64 + ((col>>3 ^ row&7) << 3 | col&7)]
+        *(float*)(wbase[(b << 2) ^ (g & 3)] + ((g & 3) + 8 * (g >> 2)) * 256) = acc[a][b][g];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = rr + 8 * i;
-      const int m = mb + row;
-      if (m >= p.M) continue;
       const f32x4* src = (const f32x4*)(ep + row * 64 + ((cg ^ (row & 7)) << 3));
       const f32x4 v0 = src[0], v1 = src[1];
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
-      float rv[8], mv[8];
-      if (ES == 2) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          rv[2 * j] = bf2f(rres[i][0][j] & 0xffff); rv[2 * j + 1] = bf2f(rres[i][0][j] >> 16);
-          mv[2 * j] = bf2f(rmsk[i][0][j] & 0xffff); mv[2 * j + 1] = bf2f(rmsk[i][0][j] >> 16);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          rv[j] = __builtin_bit_cast(f32x4, rres[i][0])[j]; rv[4 + j] = __builtin_bit_cast(f32x4, rres[i][ES / 2 - 1])[j];
-          mv[j] = __builtin_bit_cast(f32x4, rmsk[i][0])[j]; mv[4 + j] = __builtin_bit_cast(f32x4, rmsk[i][ES / 2 - 1])[j];
-        }
-      }
       if (p.residual) {
+        if (ES == 2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += rv[j];
-      }
-      if (p.relu) {
+          for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(rres_[i][0][j] & 0xffff); v[2 * j + 1] += bf2f(rres_[i][0][j] >> 16); }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          for (int j = 0; j < 4; ++j) {
+            v[j] += __builtin_bit_cast(f32x4, rres_[i][0])[j]; v[4 + j] += __builtin_bit_cast(f32x4, rres_[i][ES / 2 - 1])[j];
+          }
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "s"(relu_floor));   // (fmaxf adds a canonicalising op per element)
       if (p.relu_mask) {
+        float mv[8];
+        if (ES == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { mv[2 * j] = bf2f(rmsk_[i][0][j] & 0xffff); mv[2 * j + 1] = bf2f(rmsk_[i][0][j] >> 16); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            mv[j] = __builtin_bit_cast(f32x4, rmsk_[i][0])[j]; mv[4 + j] = __builtin_bit_cast(f32x4, rmsk_[i][ES / 2 - 1])[j];
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
       }
-      if (p.out_f32 || ES == 4) {
-        f32x4* dst = (f32x4*)(p.y + ((long)m * p.ldy + n) * 4);
-        const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-        dst[0] = o0; dst[1] = o1;
+      const unsigned so = (unsigned)((a * 32 + 8 * i) * p.ldy * eso);
+      if (f32out) {
+        const u32x4 o0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+        const u32x4 o1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(o0, ry, vy, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, ry, vy, so + 16, 0);
       } else {
         const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        *(u32x4*)(p.y + ((long)m * p.ldy + n) * 2) = o;
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, 0);
       }
     }
     if (DEPTH == 2 && a + 2 < 4) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
