@@ -1929,8 +1929,9 @@ static bool use_gemm256(const ConvArgs& a) {
   if (a.pool || (a.cpp & 7) || (a.Cout & 255) || !vec_ok || a.KH * a.KW > 31) return false;
   if (2 * a.pad > a.KH - 1 || 2 * a.pad > a.KW - 1) return false;   // rows of a tile must ascend in memory (per-block buffer base)
   if (mode == 2) return true;                                   // forced (tests)
+  // (per-shape A/B inside the training step: 196 tiles (M 25088, N 512) run 1.3-1.5x faster here, 100 tiles and fewer slower)
   const long tiles = (long)((a.M + 255) / 256) * (a.Cout / 256) * g_batch_peek();
-  return tiles >= 224;
+  return tiles >= 160;
 }
 
 
@@ -2002,7 +2003,9 @@ static bool wgrad256_ok(const WgradArgs& a, int batch) {
   if ((a.Cout & 255) || (a.K & 255) || (a.cpp & 7) || (a.ldd & 7)) return false;
   if (mode == 2) return true;
   // long reductions only: each block ends with 64 Ki scalar atomics, which a short m range cannot amortise
-  return (long)(a.Cout / 256) * (a.K / 256) * batch * ((a.M + WM - 1) / WM) >= 32768;
+  // (threshold from per-shape A/B inside the training step: 9342 (M 66400, 256 x 2304) and 14112 (M 25088, 512 x 4608) run
+  // 1.6x faster here than on the 128x128 kernel, 8300 (M 265600, 512 x 256) and everything below run slower)
+  return (long)(a.Cout / 256) * (a.K / 256) * batch * ((a.M + WM - 1) / WM) >= 9000;
 }
 // buffer addressing: lane offset + soffset must stay below 2 GiB inside one block's reduction range
 static bool wgrad256_span_ok(const WgradArgs& a) {
