@@ -62,8 +62,8 @@ def cpu_baseline(height, width, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
@@ -96,16 +96,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # HIP events cost: a pair around every one of the step's ~1000 library launches slows the step by ~5 % (142 vs 135 ms),
+    # so the timed region carries events only on the launches of the DOMINANT kernel (the roofline object's `achieved`);
+    # which kernel that is, and the per-kernel table, come from one fully instrumented untimed step (the last warm-up step).
+    full = None
+    for i in range(args.warmup):
+        if i == args.warmup - 1:
+            hip.PROFILE.enable()
         tr.run_step()
+    if args.warmup > 0:
+        full = hip.PROFILE.collect()
+    gemm_names = ("k_conv_fwd256", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma")
+    dom_name = "k_conv_fwd256"
+    if full:
+        rows = [k for k in gemm_names if k in full]
+        if rows:
+            dom_name = max(rows, key=lambda k: full[k]["ms"])
     barrier()
-    hip.PROFILE.enable()
+    hip.PROFILE.enable(only={dom_name})
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = tr.run_step()
     barrier()
     dt = time.perf_counter() - t0
     prof = hip.PROFILE.collect()
+    if full is None:                                   # --warmup 0: the instrumented step runs after the timed region
+        hip.PROFILE.enable()
+        tr.run_step()
+        full = hip.PROFILE.collect()
     # RN50-C4 supervised FORWARD alone (backbone to res4, RPN, RoIAlign, RoI layer4, attention pool, classifier, losses), the
     # quantity BASELINE.json's roofline target is stated on: algorithmic 1.878 TFLOP per 800x1333 image (SURVEY.md 8(d):
     # 938.8 GMAC, query-0-only attention pool), timed outside the step timing above, rank 0's own clock
@@ -129,10 +147,9 @@ def main():
 
     if rank == 0:
         gb = args.batch * world
-        # dominant kernel = the single kernel with the most device time (k_conv_fwd256 on this workload); the C-ABI reports
-        # which kernel each conv / GEMM entry point launched (cddmsl_last_kernel), so a profiler row is one kernel
-        gemm_rows = [k for k in ("k_conv_fwd256", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma") if k in prof]
-        dom_name = max(gemm_rows, key=lambda k: prof[k]["ms"]) if gemm_rows else "k_conv_fwd256"
+        # dominant kernel = the single kernel with the most device time in the instrumented step (k_conv_fwd256 on this
+        # workload); the C-ABI reports which kernel a conv / GEMM entry point launches (cddmsl_last_kernel / cddmsl_plan_only),
+        # so a profiler row is one kernel, and `dom` holds the HIP-event times of that kernel's launches in the TIMED steps
         dom = prof.get(dom_name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
         # HBM traffic per launch of that kernel from the PMC passes (tools/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE)
         traffic = None
@@ -157,8 +174,9 @@ def main():
                          "algorithmic_flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                          "launches_per_step": dom["launches"] / max(args.steps, 1),
                          "kernel_ms_per_step": dom["ms"] / max(args.steps, 1)},
-            "kernels_ms_per_step": {k: round(v["ms"] / max(args.steps, 1), 3) for k, v in prof.items()},
-            "kernels_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in prof.items() if v["ms"] > 0 and v["flops"] > 0},
+            "kernels_ms_per_step": {k: round(v["ms"], 3) for k, v in full.items()},
+            "kernels_ms_note": "one fully instrumented untimed step (event pairs on every launch: that step runs ~5 % slower)",
+            "kernels_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in full.items() if v["ms"] > 0 and v["flops"] > 0},
             "losses": losses,
         }
         if fwd_ms is not None:

@@ -1564,6 +1564,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
 }
 
 static thread_local int g_last_kernel = 0;   // which kernel the last conv/GEMM entry point of this thread launched (cddmsl_last_kernel)
+static thread_local int g_plan_only = 0;     // cddmsl_plan_only(1): entry points choose their kernel (g_last_kernel) and return without launching
 static thread_local int g_batch = 1;   // set by the batched entry point around its launch
 static inline int g_batch_peek() { return g_batch; }
 
@@ -1944,6 +1945,7 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   if (!a.pool && a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.cpp == 1 || a.cpp == 4) && (a.Cout == 32 || a.Cout == 64) &&
       !a.residual && !a.relu_mask && !a.out_f32 && g_batch == 1 && a.xrs == a.cpp && a.wrs == a.Kc) {
     g_last_kernel = 8;
+    if (g_plan_only) return CDDMSL_OK;
     const int nb = 256 * 8;                       // 8 blocks of 4 waves per CU, grid-stride over 32-pixel tiles
     if (a.cpp == 1 && a.Cout == 32) hipLaunchKernelGGL((k_conv3x3_small<T, 1, 1>), dim3(nb), dim3(256), 0, st, a);
     else if (a.cpp == 1) hipLaunchKernelGGL((k_conv3x3_small<T, 1, 2>), dim3(nb), dim3(256), 0, st, a);
@@ -1954,18 +1956,20 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   if (use_gemm256(a)) {
     grid = (long)(a.Cout / 256) * ((a.M + 255) / 256);
     g_last_kernel = 3;
+    if (g_plan_only) return CDDMSL_OK;
     if (a.KH == 1 && a.KW == 1 && a.pad == 0)
       hipLaunchKernelGGL((k_conv_fwd256<T, false>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
     else
       hipLaunchKernelGGL((k_conv_fwd256<T, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
-  } else if (a.pool) { g_last_kernel = 2; hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a); }
-  else { g_last_kernel = 1; hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid, (unsigned)g_batch), dim3(256), 0, st, a); }
+  } else if (a.pool) { g_last_kernel = 2; if (g_plan_only) return CDDMSL_OK; hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a); }
+  else { g_last_kernel = 1; if (g_plan_only) return CDDMSL_OK; hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid, (unsigned)g_batch), dim3(256), 0, st, a); }
   return launch_status();
 }
 
 }  // namespace
 
 extern "C" int cddmsl_last_kernel(void) { return g_last_kernel; }
+extern "C" int cddmsl_plan_only(int on) { const int was = g_plan_only; g_plan_only = on; return was; }
 
 extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias,
                                const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin,
@@ -2076,12 +2080,14 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
     sp = (total_mt + a.mtiles_per_split - 1) / a.mtiles_per_split;
     if (wgrad256_span_ok(a)) {
       g_last_kernel = 6;
+      if (g_plan_only) return CDDMSL_OK;
       hipLaunchKernelGGL(k_wgrad256, dim3((unsigned)(tiles2 * sp)), dim3(512), 0, (hipStream_t)stream, a);
       return launch_status();
     }
     a.mtiles_per_split = keep;
   }
   g_last_kernel = same ? 5 : 4;
+  if (g_plan_only) return CDDMSL_OK;
   if (same) {
     if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
@@ -2150,6 +2156,7 @@ extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, i
     if (bpb > batch) bpb = batch;
     const unsigned gy = (unsigned)((batch + bpb - 1) / bpb);
     g_last_kernel = 9;
+    if (g_plan_only) return CDDMSL_OK;
 #define CDDMSL_TNS(NG)                                                                                                               \
   case NG:                                                                                                                           \
     if (mode == 0) hipLaunchKernelGGL((k_gemm_tn_small<NG, 0>), dim3((unsigned)kt, gy), dim3(256), 0, (hipStream_t)stream, p, batch, (int)bpb);      \
@@ -2167,6 +2174,7 @@ extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, i
     if (bpb > batch) bpb = batch;
     const unsigned gy = (unsigned)((batch + bpb - 1) / bpb);
     g_last_kernel = 7;
+    if (g_plan_only) return CDDMSL_OK;
     if (dtype == 0) hipLaunchKernelGGL(k_gemm_tn_stream<__bf16>, dim3((unsigned)tiles, gy), dim3(256), 0, (hipStream_t)stream, p, batch, (int)bpb);
     else hipLaunchKernelGGL(k_gemm_tn_stream<float>, dim3((unsigned)tiles, gy), dim3(256), 0, (hipStream_t)stream, p, batch, (int)bpb);
     return launch_status();
@@ -2176,6 +2184,7 @@ extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, i
   long grid = tiles * splits;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   g_last_kernel = 5;
+  if (g_plan_only) return CDDMSL_OK;
   if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
   return launch_status();

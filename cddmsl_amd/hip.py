@@ -21,6 +21,7 @@ def _L():
     if not _sigs_done:
         vp, ci, cf = c_void_p, c_int, c_float
         L.cddmsl_last_kernel.argtypes = []
+        L.cddmsl_plan_only.argtypes = [ci]
         L.cddmsl_conv_fwd.argtypes = [vp] * 7 + [ci] * 16 + [vp]
         L.cddmsl_conv_wgrad.argtypes = [vp] * 4 + [ci] * 12 + [vp]
         L.cddmsl_weight_prep.argtypes = [vp] * 4 + [ci] * 5 + [vp]
@@ -70,15 +71,31 @@ class _Profiler:
 
     def __init__(self):
         self.on = False
+        self.only = None
         self.events = []
         self.shapes = []
 
-    def enable(self):
-        self.on, self.events, self.shapes = True, [], []
+    def enable(self, only=None):
+        """``only``: a set of profiler row names -- launches of other kernels record no events at all (an event pair per
+        launch on ~1000 launches costs ~5 % of the step; inside bench.py's timed region only the dominant kernel is timed)."""
+        self.on, self.only, self.events, self.shapes = True, (set(only) if only else None), [], []
 
-    def begin(self):
+    def begin(self, name=None, plan=None):
+        """``name``: the row this launch will be booked under, if known before the launch; ``plan``: a callable that runs
+        the entry point in plan-only mode (no launch) for entry points whose kernel is chosen inside the library."""
         if not self.on:
             return None
+        if self.only is not None:
+            if name is None and plan is not None:
+                L = _L()
+                L.cddmsl_plan_only(1)
+                try:
+                    plan()
+                finally:
+                    L.cddmsl_plan_only(0)
+                name = _CONV_KERNEL.get(L.cddmsl_last_kernel())
+            if name not in self.only:
+                return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
         return e
@@ -112,7 +129,7 @@ class _Profiler:
             d["bytes"] += nbytes
             d["ms"] += e0.elapsed_time(e1)
             d["launches"] += 1
-        self.on, self.events = False, []
+        self.on, self.only, self.events = False, None, []
         return out
 
 
@@ -124,7 +141,7 @@ _CONV_KERNEL = {1: "k_conv_fwd", 2: "k_conv_fwd_reg", 3: "k_conv_fwd256", 4: "k_
 def _timed(name):
     def deco(fn):
         def wrapper(*a, **k):
-            e0 = PROFILE.begin()
+            e0 = PROFILE.begin(name)
             r = fn(*a, **k)
             PROFILE.end(e0, name)
             return r
@@ -159,10 +176,12 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
     for v in (residual, relu_mask):
         assert v is None or (v.dtype == x.dtype and v.is_contiguous() and v.numel() == y.numel())
-    e0 = PROFILE.begin()
-    st = _L().cddmsl_conv_fwd(ptr(x), ptr(w), ptr(y), ptr(scale), ptr(bias), ptr(residual), ptr(relu_mask),
-                              N, H, W, Cin, Cout, KH, KW, stride, pad, int(pool), Cout, Cout, Cout,
-                              int(relu), int(out_f32), _dt(x), stream_ptr())
+    def launch():
+        return _L().cddmsl_conv_fwd(ptr(x), ptr(w), ptr(y), ptr(scale), ptr(bias), ptr(residual), ptr(relu_mask),
+                                    N, H, W, Cin, Cout, KH, KW, stride, pad, int(pool), Cout, Cout, Cout,
+                                    int(relu), int(out_f32), _dt(x), stream_ptr())
+    e0 = PROFILE.begin(plan=launch) if PROFILE.on else None
+    st = launch()
     check(st, "cddmsl_conv_fwd")
     PROFILE.end(e0, _CONV_KERNEL.get(_L().cddmsl_last_kernel(), "conv_fwd") if e0 is not None else "conv_fwd",
                 2.0 * N * Ho * Wo * Cout * KH * KW * Cin,    # algorithmic 2*M*N*K
@@ -194,9 +213,11 @@ def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None
     if out is None:
         out = torch.zeros(w_shape, device=x.device, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(w_shape)
-    e0 = PROFILE.begin()
-    st = _L().cddmsl_conv_wgrad(ptr(x), ptr(dy), ptr(out), ptr(scale), N, H, W, Cin, Cout, KH, KW, stride, pad,
-                                int(pool), Cout, _dt(x), stream_ptr())
+    def launch():
+        return _L().cddmsl_conv_wgrad(ptr(x), ptr(dy), ptr(out), ptr(scale), N, H, W, Cin, Cout, KH, KW, stride, pad,
+                                      int(pool), Cout, _dt(x), stream_ptr())
+    e0 = PROFILE.begin(plan=launch) if PROFILE.on else None
+    st = launch()
     check(st, "cddmsl_conv_wgrad")
     PROFILE.end(e0, _CONV_KERNEL.get(_L().cddmsl_last_kernel(), "conv_wgrad") if e0 is not None else "conv_wgrad",
                 2.0 * (dy.numel() // Cout) * Cout * KH * KW * Cin,

@@ -51,6 +51,10 @@ int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, int M, int N
  * 2 k_conv_fwd_reg (fused avg-pool loader), 3 k_conv_fwd256 (256x256 ping-pong), 4 k_conv_wgrad, 5 k_conv_wgrad_dma,
  * 6 k_wgrad256, 7 k_gemm_tn_stream, 8 k_conv3x3_small (few-channel 3x3 layers: the CLIP stem), 9 k_gemm_tn_small.  bench.py uses it to attribute HIP-event times to kernels. */
 int cddmsl_last_kernel(void);
+/* diagnostic: while on (per thread), the conv / GEMM entry points above choose their kernel (cddmsl_last_kernel) and return
+ * without launching; bench.py asks this way BEFORE a launch whether it is the kernel whose launches it is timing, so only those
+ * launches carry HIP events inside the timed region.  Returns the previous setting. */
+int cddmsl_plan_only(int on);
 /* f32 master -> `dtype` forward weights and flipped/transposed dgrad weights scaled by the FrozenBN scale */
 int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int Cout, int KH, int KW, int Cin,
                        int dtype, void* stream);
