@@ -58,6 +58,7 @@ struct ConvArgs {
   int Nimg, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int ldy, ldr, ldm;
   int relu, out_f32, pool;
+  int res_f32;     // residual rows are f32 although T is bf16 (f32 output only): the mapper's f32 residual stream
   int M, Kc, cpp;  // rows, total K chunks, chunks per pixel
   FastDiv dWo, dHo, dcpp, dKW;
   int xrs, wrs;    // row strides in 16-byte chunks: A pixel -> pixel (default cpp), B row -> row (default Kc)
@@ -460,7 +461,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
   const bool vec_ok = (p.Cout % 8 == 0) && (p.ldy % 8 == 0) && (!p.residual || p.ldr % 8 == 0) && (!p.relu_mask || p.ldm % 8 == 0);
   constexpr bool PRE = Mma<T>::ES == 2;
   u32x4 rres[2][4], rmsk[2][4];
-  if (PRE && vec_ok && (p.residual || p.relu_mask)) {
+  const bool rf32 = PRE && p.res_f32;             // f32 residual rows on the bf16 kernel: read in the epilogue
+  if (PRE && vec_ok && ((p.residual && !rf32) || p.relu_mask)) {
     const int n = n0 + wn * 64 + (lane & 7) * 8;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
         int m = m0 + wm * 64 + a * 32 + (lane >> 3) + 8 * i;
         bool ok = m < p.M && n < p.Cout;
         const u32x4 z = {0u, 0u, 0u, 0u};
-        rres[a][i] = (ok && p.residual) ? *(const u32x4*)(p.residual + ((long)m * p.ldr + n) * 2) : z;
+        rres[a][i] = (ok && p.residual && !rf32) ? *(const u32x4*)(p.residual + ((long)m * p.ldr + n) * 2) : z;
         rmsk[a][i] = (ok && p.relu_mask) ? *(const u32x4*)(p.relu_mask + ((long)m * p.ldm + n) * 2) : z;
       }
   }
@@ -549,7 +551,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
           for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
           if (p.residual) {
             float rv[8];
-            if (PRE) {
+            if (rf32) load8<float>(p.residual + ((long)m * p.ldr + n) * 4, rv);
+            else if (PRE) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) { rv[2 * j] = bf2f(rres[a][i][j] & 0xffff); rv[2 * j + 1] = bf2f(rres[a][i][j] >> 16); }
             } else load8<T>(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES, rv);
@@ -1835,9 +1838,11 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)m0 * ld * es), 0, base ? (int)bytes : 0, 0x00020000);
   };
-  const __amdgpu_buffer_rsrc_t ry = mk(p.y, p.ldy, eso), rres = mk(p.residual, p.ldr, ES), rmsk = mk(p.relu_mask, p.ldm, ES);
+  const bool rf32 = ES == 2 && p.res_f32;         // f32 residual rows on the bf16 kernel (the mapper's f32 residual stream)
+  const int esr = rf32 ? 4 : ES;
+  const __amdgpu_buffer_rsrc_t ry = mk(p.y, p.ldy, eso), rres = mk(p.residual, p.ldr, esr), rmsk = mk(p.relu_mask, p.ldm, ES);
   const unsigned vy = (unsigned)(((wr * 128 + rr) * p.ldy + n) * eso);
-  const unsigned vr = (unsigned)(((wr * 128 + rr) * p.ldr + n) * ES), vm = (unsigned)(((wr * 128 + rr) * p.ldm + n) * ES);
+  const unsigned vr = (unsigned)(((wr * 128 + rr) * p.ldr + n) * esr), vm = (unsigned)(((wr * 128 + rr) * p.ldm + n) * ES);
   // bf16: residual / mask rows are fetched TWO passes ahead (two register sets, static indices): with one block per CU
   // nothing else hides their HBM latency.  The f32 parity instantiation (twice the registers per row) one pass ahead.
   constexpr int DEPTH = ES == 2 ? 2 : 1;
@@ -1853,14 +1858,19 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int q = 0; q < ES / 2; ++q) {       // (an absent operand is not requested at all: even a zero-sized buffer returns its zeros through the vector memory path)
-        if (p.residual) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * i) * p.ldr * ES + q * 16, 0);
+        if (p.residual && !rf32) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * i) * p.ldr * ES + q * 16, 0);
         if (p.relu_mask) rmsk_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, (a * 32 + 8 * i) * p.ldm * ES + q * 16, 0);
       }
   };
-  if (DEPTH == 2) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
+  if (DEPTH == 2 && !rf32) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     if (DEPTH == 1) fetch(a, rresb[0], rmskb[0]);
+    if (rf32) {                                   // this pass's 4 rows x 32 B, in the two bf16 register sets taken together
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        rresb[(f >> 2) % DEPTH][f & 3][0] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * (f >> 1)) * p.ldr * 4 + (f & 1) * 16, 0);
+    }
     u32x4 (*rres_)[ES / 2] = rresb[a % DEPTH];
     u32x4 (*rmsk_)[ES / 2] = rmskb[a % DEPTH];
 #pragma unroll
@@ -1877,7 +1887,13 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
-      if (p.residual) {
+      if (rf32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] += __builtin_bit_cast(f32x4, rresb[((2 * i) >> 2) % DEPTH][(2 * i) & 3][0])[j];
+          v[4 + j] += __builtin_bit_cast(f32x4, rresb[((2 * i + 1) >> 2) % DEPTH][(2 * i + 1) & 3][0])[j];
+        }
+      } else if (p.residual) {
         if (ES == 2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(rres_[i][0][j] & 0xffff); v[2 * j + 1] += bf2f(rres_[i][0][j] >> 16); }
@@ -1915,7 +1931,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
         __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, 0);
       }
     }
-    if (DEPTH == 2 && a + 2 < 4) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
+    if (DEPTH == 2 && a + 2 < 4 && !rf32) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
   }
 }
 
@@ -1987,7 +2003,11 @@ extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const floa
   if (pool) { a.Ho = Hi / 2; a.Wo = Wi / 2; }
   else { a.Ho = (Hi + 2 * pad - KH) / stride + 1; a.Wo = (Wi + 2 * pad - KW) / stride + 1; }
   if (a.Ho <= 0 || a.Wo <= 0) return CDDMSL_ERR_ARG;
-  a.ldy = ldy; a.ldr = ldr; a.ldm = ldm; a.relu = relu; a.out_f32 = out_f32; a.pool = pool;
+  // out_f32 bit 1: the residual rows are f32 (bf16 kernels, f32 output, no ReLU mask) -- the mapper's f32 residual stream
+  if ((out_f32 & 2) && (!(out_f32 & 1) || !residual || relu_mask || pool)) return CDDMSL_ERR_ARG;
+  a.ldy = ldy; a.ldr = ldr; a.ldm = ldm; a.relu = relu; a.out_f32 = out_f32 & 1; a.pool = pool;
+  a.res_f32 = (dtype == 0 && (out_f32 & 2)) ? 1 : 0;
+  if (a.res_f32 && ((Cout & 7) || (ldy & 7) || (ldr & 7))) return CDDMSL_ERR_ARG;                // (vector epilogue only)
   long M = (long)Nimg * a.Ho * a.Wo;
   if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
   a.M = (int)M; a.cpp = Cin * es / 16; a.Kc = KH * KW * a.cpp;
@@ -2111,7 +2131,7 @@ extern "C" int cddmsl_gemm_nt_batched(const void* a, const void* w, void* c, con
   ConvArgs p;
   p.x = (const char*)a; p.w = (const char*)w; p.y = (char*)c; p.scale = nullptr; p.bias = bias; p.residual = nullptr; p.relu_mask = nullptr;
   p.Nimg = 1; p.Hi = 1; p.Wi = M; p.Cin = K; p.Ho = 1; p.Wo = M; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
-  p.ldy = ldc; p.ldr = 0; p.ldm = 0; p.relu = 0; p.out_f32 = out_f32; p.pool = 0;
+  p.ldy = ldc; p.ldr = 0; p.ldm = 0; p.relu = 0; p.out_f32 = out_f32; p.pool = 0; p.res_f32 = 0;
   p.M = M; p.cpp = K * es / 16; p.Kc = p.cpp;
   p.dWo = make_fastdiv((unsigned)M); p.dHo = make_fastdiv(1u); p.dcpp = make_fastdiv((unsigned)p.cpp); p.dKW = make_fastdiv(1u);
   p.xrs = lda * es / 16; p.wrs = ldb * es / 16;

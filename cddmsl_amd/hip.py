@@ -174,12 +174,15 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
     y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
     for v in (scale, bias):
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
+    res_f32 = residual is not None and residual.dtype == torch.float32 and x.dtype != torch.float32
+    if res_f32:       # f32 residual stream on the bf16 kernels: f32 output, vector epilogue
+        assert out_f32 and relu_mask is None and not pool and Cout % 8 == 0
     for v in (residual, relu_mask):
-        assert v is None or (v.dtype == x.dtype and v.is_contiguous() and v.numel() == y.numel())
+        assert v is None or ((v.dtype == x.dtype or (v is residual and res_f32)) and v.is_contiguous() and v.numel() == y.numel())
     def launch():
         return _L().cddmsl_conv_fwd(ptr(x), ptr(w), ptr(y), ptr(scale), ptr(bias), ptr(residual), ptr(relu_mask),
                                     N, H, W, Cin, Cout, KH, KW, stride, pad, int(pool), Cout, Cout, Cout,
-                                    int(relu), int(out_f32), _dt(x), stream_ptr())
+                                    int(relu), int(out_f32) | (2 if res_f32 else 0), _dt(x), stream_ptr())
     e0 = PROFILE.begin(plan=launch) if PROFILE.on else None
     st = launch()
     check(st, "cddmsl_conv_fwd")

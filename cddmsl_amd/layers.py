@@ -113,9 +113,10 @@ class ConvFn(torch.autograd.Function):
     weights (input gradient only)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, pw, bias, stride, pad, relu, out_f32, train_w):
+    def forward(ctx, x, anchor, pw, bias, stride, pad, relu, out_f32, train_w, residual=None):
         wf, _ = pw.get(x.dtype, need_dgrad=False)
-        y = hip.conv_fwd(x, wf, None, None if bias is None else bias.detach(), relu=relu, stride=stride, pad=pad, out_f32=out_f32)
+        y = hip.conv_fwd(x, wf, None, None if bias is None else bias.detach(), None if residual is None else residual.detach(),
+                         relu=relu, stride=stride, pad=pad, out_f32=out_f32)
         ctx.pw, ctx.bias, ctx.cfg = pw, bias, (stride, pad, relu, out_f32, train_w)
         ctx.save_for_backward(x, y if relu else None)
         return y
@@ -125,6 +126,7 @@ class ConvFn(torch.autograd.Function):
         x, y = ctx.saved_tensors
         stride, pad, relu, out_f32, train_w = ctx.cfg
         T = x.dtype
+        dy_in = dy
         dy = dy.contiguous()
         if relu:
             dy = hip.relu_bwd(dy, y if y.dtype == T else y.to(T))
@@ -141,17 +143,21 @@ class ConvFn(torch.autograd.Function):
             _, wd = ctx.pw.get(T, need_dgrad=True)
             KH = _ohwi(w).shape[1]
             dx = hip.conv_fwd(dy, wd, stride=1, pad=KH - 1 - pad)
-        return dx, None, None, None, None, None, None, None, None
+        # y = conv + residual (no ReLU with a residual): the residual's gradient is the incoming one, as it came
+        return dx, None, None, None, None, None, None, None, None, (dy_in if ctx.needs_input_grad[9] else None)
 
 
-def conv(x, pw, bias=None, stride=1, pad=0, relu=False, out_f32=False, train_w=True):
+def conv(x, pw, bias=None, stride=1, pad=0, relu=False, out_f32=False, train_w=True, residual=None):
+    """``residual`` (same shape as the output; f32 with ``out_f32`` on the bf16 path) is added in the GEMM epilogue."""
     anchor = pw.param if train_w else None
-    return ConvFn.apply(x, anchor, pw, bias, stride, pad, relu, out_f32, train_w)
+    assert residual is None or not relu
+    return ConvFn.apply(x, anchor, pw, bias, stride, pad, relu, out_f32, train_w, residual)
 
 
-def linear(x2d, pw, bias=None, relu=False, out_f32=False, train_w=True):
+def linear(x2d, pw, bias=None, relu=False, out_f32=False, train_w=True, residual=None):
     M, K = x2d.shape
-    y = conv(x2d.contiguous().view(1, 1, M, K), pw, bias, 1, 0, relu, out_f32, train_w)
+    y = conv(x2d.contiguous().view(1, 1, M, K), pw, bias, 1, 0, relu, out_f32, train_w,
+             None if residual is None else residual.contiguous().view(1, 1, M, -1))
     return y.view(M, -1)
 
 

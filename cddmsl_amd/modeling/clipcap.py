@@ -20,10 +20,10 @@ class _Lin(nn.Module):
         self.bias = nn.Parameter(torch.empty(o)) if bias else None
         self._pw = None
 
-    def forward(self, x2d, relu=False, out_f32=True):
+    def forward(self, x2d, relu=False, out_f32=True, residual=None):
         if self._pw is None or self._pw.param is not self.weight:
             self._pw = layers.PreparedWeight(self.weight, None, frozen=True)
-        return layers.linear(x2d, self._pw, self.bias, relu=relu, out_f32=out_f32, train_w=False)
+        return layers.linear(x2d, self._pw, self.bias, relu=relu, out_f32=out_f32, train_w=False, residual=residual)
 
 
 class MlpTransformer(nn.Module):
@@ -90,9 +90,9 @@ class TransformerMapper(nn.Module):
                 # LayerNorm hands back its input for the residual add so that the backward accumulates in one kernel
                 y, hs = layers.layer_norm_skip(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
                 o = layers.small_attention(a.to_queries(y, out_f32=False), a.to_keys_values(y, out_f32=False), t, H, a.scale)
-                h = hs + a.project(o)
+                h = a.project(o, residual=hs)                 # the f32 residual adds ride in the GEMM epilogues
                 y, hs = layers.layer_norm_skip(h, lyr.norm2.weight, lyr.norm2.bias, T)
-                h = (hs + lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True, out_f32=False))).view(n, t, d)
+                h = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True, out_f32=False), residual=hs).view(n, t, d)
                 continue
             y = layers.layer_norm(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
             # exact-f32 parity path: the same arithmetic on torch ops (the fused kernel is bf16-only)

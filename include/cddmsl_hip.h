@@ -33,7 +33,9 @@ int cddmsl_probe_axpb(const float* x, float* y, float a, float b, long n, void* 
  * modeling/backbone/clip_backbone.py:57-70,193-219, layers/batch_norm.py:45-66,
  * modeling/proposal_generator/rpn.py:158-177, modeling/backbone/clipcap/clipcap.py:39-163.
  * y[m][n] = relu?( acc*scale[n] + bias[n] + residual[m][n] ), zeroed where relu_mask[m][n] <= 0 (ReLU backward);
- * pool=1: 1x1 conv over the 2x2 average-pooled input.  dgrad = the same entry point on weight_prep's w_dgrad. */
+ * pool=1: 1x1 conv over the 2x2 average-pooled input.  dgrad = the same entry point on weight_prep's w_dgrad.
+ * out_f32: bit 0 = y is f32; bit 1 (bf16 kernels, with bit 0, no relu_mask, leading dims multiples of 8) = the residual rows are
+ * f32 -- the mapper's residual stream x + f(LN(x)) stays f32 (clipcap.py:88-100) and its add rides in the GEMM epilogue. */
 int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias, const void* residual,
                     const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
                     int pool, int ldy, int ldr, int ldm, int relu, int out_f32, int dtype, void* stream);

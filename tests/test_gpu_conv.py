@@ -215,6 +215,39 @@ def test_conv_fwd_256_tile_kernel(case, dtype, tol, monkeypatch):
         assert (a - b).abs().max() <= tol * a.abs().max()
 
 
+@pytest.mark.parametrize("g256", ["0", "2"])
+def test_f32_residual_in_the_bf16_gemm_epilogue(g256, monkeypatch):
+    """y (f32) = x (bf16) @ W^T + bias + residual (f32): the mapper's residual stream stays f32 and its add rides in the GEMM
+    epilogue (out_f32 bit 1), on the 128x128 and on the 256x256 kernel; ragged M, with and without ReLU-free bias."""
+    from cddmsl_amd import hip
+    monkeypatch.setenv("CDDMSL_GEMM256", g256)
+    g = torch.Generator().manual_seed(71)
+    for M, K, N in ((1000, 768, 768), (333, 1536, 768), (2560, 768, 256)):
+        x = torch.randn(M, K, generator=g).bfloat16()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16()
+        b = torch.randn(N, generator=g) * 0.1
+        r = torch.randn(M, N, generator=g) * 3.0
+        ref = x.float() @ w.float().t() + b + r
+        y = hip.conv_fwd(x.cuda().view(1, 1, M, K), w.cuda().view(N, 1, 1, K), None, b.cuda(), r.cuda().view(1, 1, M, N), out_f32=True)
+        assert hip._L().cddmsl_last_kernel() == (3 if g256 == "2" else 1)
+        assert y.dtype == torch.float32
+        err = (y.view(M, N).cpu() - ref).abs().max()
+        assert err < 1e-4 * ref.abs().max() + 2e-2 * (x.float() @ w.float().t()).abs().max() * 2 ** -8, float(err)
+    # the autograd wrapper: the residual's gradient is the incoming gradient
+    from cddmsl_amd import layers
+    M, K, N = 512, 768, 768
+    wp = torch.nn.Parameter((torch.randn(N, K, generator=g) * K ** -0.5).cuda())
+    pw = layers.PreparedWeight(wp, None, frozen=True)
+    x = torch.randn(M, K, generator=g).cuda().bfloat16().requires_grad_(True)
+    r = torch.randn(M, N, generator=g).cuda().requires_grad_(True)
+    y = layers.linear(x, pw, None, out_f32=True, train_w=False, residual=r)
+    gy = torch.randn(M, N, generator=g).cuda()
+    y.backward(gy)
+    assert torch.equal(r.grad, gy)
+    dx_ref = gy.bfloat16().float() @ wp.detach().bfloat16().float()
+    assert (x.grad.float() - dx_ref).abs().max() < 2e-2 * dx_ref.abs().max()
+
+
 CASES_W256 = [
     # N, H, W, Cin, Cout, K, pad     (Cout % 256 == 0, KH*KW*Cin % 256 == 0, Cin % 64 == 0)
     (3, 14, 14, 256, 256, 3, 1),     # M = 588: ragged last reduction tile, 9 taps
