@@ -157,10 +157,12 @@ def _dt(t):
 
 
 def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=None, stride=1, pad=0,
-             pool=False, out_f32=False):
+             pool=False, out_f32=False, residual_pooled=False):
     """x NHWC [N,H,W,Cin]; w [Cout,KH,KW,Cin] (same dtype).  Returns NHWC [N,Ho,Wo,Cout].
     y = relu?(acc*scale[n] + bias[n] + residual), zeroed where relu_mask <= 0 (ReLU backward).
-    pool=True: 1x1 conv over the 2x2 average-pooled input (AvgPool2d(2) fused into the loader)."""
+    pool=True: 1x1 conv over the 2x2 average-pooled input (AvgPool2d(2) fused into the loader).
+    residual_pooled=True: ``residual`` is [N, Ho//2, Wo//2, Cout] and every output pixel adds a quarter of its pooled pixel
+    (the backward of AvgPool2d(2) fused into the epilogue; pooled tensor < 2 GiB -- see ``pooled_residual_ok``)."""
     require_cuda(x, w, scale, bias, residual, relu_mask)
     assert x.dim() == 4 and w.dim() == 4 and x.is_contiguous() and w.is_contiguous()
     assert x.dtype == w.dtype
@@ -177,12 +179,16 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
     res_f32 = residual is not None and residual.dtype == torch.float32 and x.dtype != torch.float32
     if res_f32:       # f32 residual stream on the bf16 kernels: f32 output, vector epilogue
         assert out_f32 and relu_mask is None and not pool and Cout % 8 == 0
+    if residual_pooled:
+        assert residual is not None and not res_f32 and residual.dtype == x.dtype and residual.is_contiguous()
+        assert tuple(residual.shape) == (N, Ho // 2, Wo // 2, Cout) and pooled_residual_ok(residual), residual.shape
     for v in (residual, relu_mask):
-        assert v is None or ((v.dtype == x.dtype or (v is residual and res_f32)) and v.is_contiguous() and v.numel() == y.numel())
+        assert v is None or (v is residual and residual_pooled) or (
+            (v.dtype == x.dtype or (v is residual and res_f32)) and v.is_contiguous() and v.numel() == y.numel())
     def launch():
         return _L().cddmsl_conv_fwd(ptr(x), ptr(w), ptr(y), ptr(scale), ptr(bias), ptr(residual), ptr(relu_mask),
                                     N, H, W, Cin, Cout, KH, KW, stride, pad, int(pool), Cout, Cout, Cout,
-                                    int(relu), int(out_f32) | (2 if res_f32 else 0), _dt(x), stream_ptr())
+                                    int(relu), int(out_f32) | (2 if res_f32 else 0) | (4 if residual_pooled else 0), _dt(x), stream_ptr())
     e0 = PROFILE.begin(plan=launch) if PROFILE.on else None
     st = launch()
     check(st, "cddmsl_conv_fwd")
@@ -194,6 +200,11 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
                              + (residual.numel() * residual.element_size() if residual is not None else 0)
                              + (relu_mask.numel() * relu_mask.element_size() if relu_mask is not None else 0)))
     return y
+
+
+def pooled_residual_ok(t):
+    """the fused AvgPool2d(2)-backward residual is buffer-addressed from the tensor base: below 2 GiB, rows of whole 16-B chunks"""
+    return t.numel() * t.element_size() < 2 ** 31 and t.shape[-1] % 8 == 0
 
 
 def linear_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=None, out_f32=False):

@@ -11,6 +11,7 @@ Conventions
 """
 import weakref
 
+
 import torch
 
 from . import hip
@@ -266,15 +267,20 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x):
         hip.conv_wgrad(px if pool else x, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
     if not need_dx:
         return None
+    pooled = False
     if wdp is not None:
         _, wdd = bp.pw[3].get(T, True)
         dxb = hip.conv_fwd(gs, wdd)
         if pool:
-            dxb = hip.avgpool2_bwd(dxb, tuple(x.shape))
+            # the downsample path's input gradient stays at pooled resolution: conv1's dgrad epilogue adds a quarter of each
+            # row's pooled pixel (AvgPool2d backward fused; saves writing and re-reading the full-resolution tensor)
+            pooled = x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and hip.pooled_residual_ok(dxb)
+            if not pooled:
+                dxb = hip.avgpool2_bwd(dxb, tuple(x.shape))
     else:
         dxb = gs
     _, w1d = bp.pw[0].get(T, True)
-    return hip.conv_fwd(dpre1, w1d, residual=dxb, relu_mask=x if mask_x else None)
+    return hip.conv_fwd(dpre1, w1d, residual=dxb, relu_mask=x if mask_x else None, residual_pooled=pooled)
 
 
 class ResStageFn(torch.autograd.Function):

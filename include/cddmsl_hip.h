@@ -35,7 +35,9 @@ int cddmsl_probe_axpb(const float* x, float* y, float a, float b, long n, void* 
  * y[m][n] = relu?( acc*scale[n] + bias[n] + residual[m][n] ), zeroed where relu_mask[m][n] <= 0 (ReLU backward);
  * pool=1: 1x1 conv over the 2x2 average-pooled input.  dgrad = the same entry point on weight_prep's w_dgrad.
  * out_f32: bit 0 = y is f32; bit 1 (bf16 kernels, with bit 0, no relu_mask, leading dims multiples of 8) = the residual rows are
- * f32 -- the mapper's residual stream x + f(LN(x)) stays f32 (clipcap.py:88-100) and its add rides in the GEMM epilogue. */
+ * f32 -- the mapper's residual stream x + f(LN(x)) stays f32 (clipcap.py:88-100) and its add rides in the GEMM epilogue;
+ * bit 2 (leading dims multiples of 8, pooled tensor < 2 GiB) = `residual` is [Nimg][Ho/2][Wo/2][ldr] and row m adds a quarter
+ * of its pooled pixel: the backward of the Bottleneck's AvgPool2d(stride) on the downsample path (clip_backbone.py:45-52). */
 int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias, const void* residual,
                     const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
                     int pool, int ldy, int ldr, int ldm, int relu, int out_f32, int dtype, void* stream);

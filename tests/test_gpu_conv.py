@@ -248,6 +248,33 @@ def test_f32_residual_in_the_bf16_gemm_epilogue(g256, monkeypatch):
     assert (x.grad.float() - dx_ref).abs().max() < 2e-2 * dx_ref.abs().max()
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("g256", ["0", "2"])
+def test_pooled_residual_is_avgpool_backward(g256, dtype, tol, monkeypatch):
+    """out_f32 bit 2: the residual operand is a 2x2-average-pooled gradient and every output pixel adds a quarter of its
+    pooled pixel -- conv1's dgrad with the downsample path's gradient (clip_backbone.py:45-52,57-70) without materialising
+    avgpool2_bwd's output.  Must equal the two-kernel form bit for bit (x 0.25 is exact), on both kernels, even and odd
+    sizes (an odd size's last row / column has no pooled pixel), with and without the ReLU mask."""
+    from cddmsl_amd import hip
+    monkeypatch.setenv("CDDMSL_GEMM256", g256)
+    g = torch.Generator().manual_seed(81)
+    for (N, H, W, Cin, Cout) in ((40, 14, 14, 64, 256), (3, 15, 21, 128, 256), (2, 50, 84, 64, 512)):
+        x = torch.randn(N, H, W, Cin, generator=g).to(dtype).cuda()
+        w = (torch.randn(Cout, 1, 1, Cin, generator=g) * Cin ** -0.5).to(dtype).cuda()
+        gp = torch.randn(N, H // 2, W // 2, Cout, generator=g).to(dtype).cuda()
+        msk = torch.randn(N, H, W, Cout, generator=g).to(dtype).cuda()
+        up = hip.avgpool2_bwd(gp, (N, H, W, Cout))
+        for m in (None, msk):
+            two = hip.conv_fwd(x, w, residual=up, relu_mask=m)
+            one = hip.conv_fwd(x, w, residual=gp, relu_mask=m, residual_pooled=True)
+            # (the 256x256 kernel's pooled variant is bf16 only; f32 stays on the 128x128 kernel even when forced)
+            assert hip._L().cddmsl_last_kernel() == (3 if g256 == "2" and dtype == torch.bfloat16 else 1)
+            assert torch.equal(one, two), (N, H, W, m is not None)
+        ref = (x.float().view(-1, Cin) @ w.float().view(Cout, Cin).t()).view(N, H, W, Cout)
+        ref[:, : H // 2 * 2, : W // 2 * 2] += 0.25 * gp.float().repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+        assert (one.float() * 0 + hip.conv_fwd(x, w, residual=gp, residual_pooled=True).float() - ref).abs().max() < tol * ref.abs().max()
+
+
 CASES_W256 = [
     # N, H, W, Cin, Cout, K, pad     (Cout % 256 == 0, KH*KW*Cin % 256 == 0, Cin % 64 == 0)
     (3, 14, 14, 256, 256, 3, 1),     # M = 588: ragged last reduction tile, 9 taps
