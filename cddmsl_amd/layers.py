@@ -11,7 +11,6 @@ Conventions
 """
 import weakref
 
-
 import torch
 
 from . import hip
