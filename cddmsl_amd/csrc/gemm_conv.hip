@@ -1977,6 +1977,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
       }
     }
     if (DEPTH == 2 && a + 2 < 4 && !rf32) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
+    // compiler fence: the next pass's float stores into `ep` must stay behind this pass's f32x4 loads from it (type-based
+    // alias analysis treats them as unrelated; hoisted stores overwrote the last rows of a pass in one instantiation)
+    asm volatile("" ::: "memory");
   }
 }
 
@@ -1989,8 +1992,9 @@ static bool use_gemm256(const ConvArgs& a) {
   if (mode == 0) return false;
   const bool vec_ok = (a.ldy % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.relu_mask || a.ldm % 8 == 0);
   if (a.pool || (a.cpp & 7) || (a.Cout & 255) || !vec_ok || a.KH * a.KW > 31) return false;
-  // the pooled-residual variant of this kernel is bf16 only: its exact-f32 instantiation mis-adds a few elements (rows 25-31 of
-  // a pass, first column of a lane; not understood) -- the f32 parity path takes the 128x128 kernel, which is bit-exact there
+  // The pooled-residual variant of this kernel is bf16 only: in its exact-f32 instantiation the first of a lane's 8 outputs is
+  // overwritten by the integer 27 in lanes with (lane & 12) == 12 of a pass's last row group (cause not found; a compiler
+  // fence between the passes did not change it) -- the f32 parity path takes the 128x128 kernel, which is bit-exact there.
   if (a.res_pool && a.cpp * 16 != a.Cin * 2) return false;
   if (2 * a.pad > a.KH - 1 || 2 * a.pad > a.KW - 1) return false;   // rows of a tile must ascend in memory (per-block buffer base)
   if (mode == 2) return true;                                   // forced (tests)
