@@ -1975,6 +1975,12 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
         const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
         __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, 0);
       }
+      // Store-data hazard (observed, gfx950): hipcc may put a vector-ALU write to the FIRST data register of a
+      // buffer_store_dwordx4 ... soffset offen directly behind the store (it did: v_mul_hi_u32 of the next row's pooled-pixel
+      // division), and lanes 12-15 of every 16 then stored that instruction's result instead of the output.  Nothing may
+      // follow the store for a few cycles.
+      asm volatile("s_nop 4" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (DEPTH == 2 && a + 2 < 4 && !rf32) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
     // compiler fence: the next pass's float stores into `ep` must stay behind this pass's f32x4 loads from it (type-based
@@ -1992,10 +1998,6 @@ static bool use_gemm256(const ConvArgs& a) {
   if (mode == 0) return false;
   const bool vec_ok = (a.ldy % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.relu_mask || a.ldm % 8 == 0);
   if (a.pool || (a.cpp & 7) || (a.Cout & 255) || !vec_ok || a.KH * a.KW > 31) return false;
-  // The pooled-residual variant of this kernel is bf16 only: in its exact-f32 instantiation the first of a lane's 8 outputs is
-  // overwritten by the integer 27 in lanes with (lane & 12) == 12 of a pass's last row group (cause not found; a compiler
-  // fence between the passes did not change it) -- the f32 parity path takes the 128x128 kernel, which is bit-exact there.
-  if (a.res_pool && a.cpp * 16 != a.Cin * 2) return false;
   if (2 * a.pad > a.KH - 1 || 2 * a.pad > a.KW - 1) return false;   // rows of a tile must ascend in memory (per-block buffer base)
   if (mode == 2) return true;                                   // forced (tests)
   // (per-shape A/B inside the training step: 196 tiles (M 25088, N 512) run 1.3-1.5x faster here, 100 tiles and fewer slower)
@@ -2025,10 +2027,9 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
     grid = (long)(a.Cout / 256) * ((a.M + 255) / 256);
     g_last_kernel = 3;
     if (g_plan_only) return CDDMSL_OK;
-    if (a.res_pool) {
-      if (Mma<T>::ES != 2) return CDDMSL_ERR_ARG;      // (use_gemm256 keeps f32 off this variant)
-      hipLaunchKernelGGL((k_conv_fwd256<__bf16, false, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
-    } else if (a.KH == 1 && a.KW == 1 && a.pad == 0)
+    if (a.res_pool)
+      hipLaunchKernelGGL((k_conv_fwd256<T, false, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
+    else if (a.KH == 1 && a.KW == 1 && a.pad == 0)
       hipLaunchKernelGGL((k_conv_fwd256<T, false>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
     else
       hipLaunchKernelGGL((k_conv_fwd256<T, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);

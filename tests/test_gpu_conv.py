@@ -267,8 +267,7 @@ def test_pooled_residual_is_avgpool_backward(g256, dtype, tol, monkeypatch):
         for m in (None, msk):
             two = hip.conv_fwd(x, w, residual=up, relu_mask=m)
             one = hip.conv_fwd(x, w, residual=gp, relu_mask=m, residual_pooled=True)
-            # (the 256x256 kernel's pooled variant is bf16 only; f32 stays on the 128x128 kernel even when forced)
-            assert hip._L().cddmsl_last_kernel() == (3 if g256 == "2" and dtype == torch.bfloat16 else 1)
+            assert hip._L().cddmsl_last_kernel() == (3 if g256 == "2" else 1)
             assert torch.equal(one, two), (N, H, W, m is not None)
         ref = (x.float().view(-1, Cin) @ w.float().view(Cout, Cin).t()).view(N, H, W, Cout)
         ref[:, : H // 2 * 2, : W // 2 * 2] += 0.25 * gp.float().repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
