@@ -224,24 +224,36 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(const char* dy, const flo
     if (py0 + TS - 1 < f[0] || py0 > f[1] || px0 + TS - 1 < f[2] || px0 > f[3]) continue;   // uniform across the block
     const float* ayr = ay + ((long)k * H + py0) * ph;
     const float* axr = ax + ((long)k * W + px0) * pw;
-    float wy[TS][MAXP], wx[TS][MAXP];
+    // Lane l of every wave holds the weights of bin row l / bin column l for the tile's TS pixel rows / columns (2 + 2 loads
+    // per thread; the first version loaded all 4*14 weights in every thread and walked all 14 x 14 bins testing for zeros:
+    // the kernel was bound by that control flow, not by the 3.3 GB of dY).  A ballot gives the bins that reach the tile;
+    // the loops below visit only those, in the same ascending (bin row, bin column) order, reading the block-uniform
+    // weights back with v_readlane.
+    const int lane = threadIdx.x & 63;
+    float wyv[TS], wxv[TS];
+    bool nzy = false, nzx = false;
 #pragma unroll
     for (int a = 0; a < TS; ++a) {
-      for (int i = 0; i < ph; ++i) wy[a][i] = (py0 + a < H) ? ayr[a * ph + i] : 0.f;
-      for (int j = 0; j < pw; ++j) wx[a][j] = (px0 + a < W) ? axr[a * pw + j] : 0.f;
+      wyv[a] = (lane < ph && py0 + a < H) ? ayr[a * ph + lane] : 0.f;
+      wxv[a] = (lane < pw && px0 + a < W) ? axr[a * pw + lane] : 0.f;
+      nzy |= wyv[a] != 0.f; nzx |= wxv[a] != 0.f;
     }
-    for (int i = 0; i < ph; ++i) {
+    unsigned long long ym = __ballot(nzy);
+    const unsigned long long xm0 = __ballot(nzx);
+    if (xm0 == 0ull) continue;
+    while (ym) {
+      const int i = __builtin_ctzll(ym);
+      ym &= ym - 1;
       float wyi[TS];
-      bool anyy = false;
 #pragma unroll
-      for (int a = 0; a < TS; ++a) { wyi[a] = wy[a][i]; anyy |= wyi[a] != 0.f; }
-      if (!anyy) continue;
-      for (int j = 0; j < pw; ++j) {
+      for (int a = 0; a < TS; ++a) wyi[a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyv[a]), i));
+      unsigned long long xm = xm0;
+      while (xm) {
+        const int j = __builtin_ctzll(xm);
+        xm &= xm - 1;
         float wxj[TS];
-        bool anyx = false;
 #pragma unroll
-        for (int a = 0; a < TS; ++a) { wxj[a] = wx[a][j]; anyx |= wxj[a] != 0.f; }
-        if (!anyx) continue;
+        for (int a = 0; a < TS; ++a) wxj[a] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wxv[a]), j));
         const u32x4* src = (const u32x4*)dy + (((long)k * ph + i) * pw + j) * cch;
         float v[NC][8];
 #pragma unroll
