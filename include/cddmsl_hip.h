@@ -78,6 +78,9 @@ int cddmsl_roi_align_backward(const void* dy, const float* rois, const int* roi_
  * modeling/proposal_generator/proposal_utils.py:22-130, layers/nms.py:19-39 (torchvision nms),
  * structures/boxes.py:322-367 + modeling/matcher.py:61-126 */
 int cddmsl_anchors(const float* cell, float* out, int Hf, int Wf, int A, float stride, float offset, void* stream);
+/* stable descending sort of every row of keys_in [N][total] (torch.sort(descending=True, stable=True) per image,
+ * proposal_utils.py:66-70): one device-wide radix sort over (image, score) composite keys; `offsets` is unused (dense rows);
+ * temp == NULL returns the workspace size in *temp_bytes */
 int cddmsl_sort_desc(const float* keys_in, float* keys_out, int* idx_scratch, int* order_out, const int* offsets, int N,
                      int total, void* temp, size_t* temp_bytes, void* stream);
 int cddmsl_rpn_decode(const int* order, const float* deltas, const float* cell, const int* img_hw, float* boxes,
