@@ -242,18 +242,23 @@ __global__ void k_attn_tokens_fwd(const char* x, const float* pos, char* tok, in
     for (int p = P + 1; p < TP; ++p) ((u32x4*)tok)[(k * TP + p) * cch + c] = z;
   }
 }
-// dx[k][p] = dtok[k][p+1] + dtok[k][0]/P
+// dx[k][p] = dtok[k][p+1] + dtok[k][0]/P, zeroed where relu_mask[k][p] <= 0 (relu_mask = the pooled map itself when it is the
+// output of a ReLU: the ReLU backward of the residual stage in front of the pool rides in this pass)
 template <typename T>
-__global__ void k_attn_tokens_bwd(const char* dtok, char* dx, int K, int P, int TP, int cch) {
+__global__ void k_attn_tokens_bwd(const char* dtok, const char* relu_mask, char* dx, int K, int P, int TP, int cch) {
   long total = (long)K * P * cch;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = i % cch; long q = i / cch;
     int p = q % P; long k = q / P;
-    float a[8], b[8], o[8];
+    float a[8], b[8], m[8], o[8];
     Elt<T>::unpack(((const u32x4*)dtok)[(k * TP + p + 1) * cch + c], a);
     Elt<T>::unpack(((const u32x4*)dtok)[(k * TP) * cch + c], b);
+    if (relu_mask) Elt<T>::unpack(((const u32x4*)relu_mask)[i], m);
 #pragma unroll
-    for (int j = 0; j < Elt<T>::VEC; ++j) o[j] = a[j] + b[j] / (float)P;
+    for (int j = 0; j < Elt<T>::VEC; ++j) {
+      o[j] = a[j] + b[j] / (float)P;
+      if (relu_mask && !(m[j] > 0.f)) o[j] = 0.f;
+    }
     ((u32x4*)dx)[i] = Elt<T>::pack(o);
   }
 }
@@ -456,13 +461,14 @@ extern "C" int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok
   return launch_status();
 }
 
-extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, void* dx, int K, int P, int TP, int C, int dtype, void* stream) {
+extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, const void* relu_mask, void* dx, int K, int P, int TP, int C, int dtype,
+                                      void* stream) {
   int es = dtype == 0 ? 2 : 4;
   if ((C * es) % 16 || P <= 0 || TP < P + 1) return CDDMSL_ERR_ARG;
   int cch = C * es / 16;
   long total = (long)K * P * cch;
   if (total == 0) return CDDMSL_OK;
-  DISPATCH(dtype, k_attn_tokens_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (char*)dx, K, P, TP, cch));
+  DISPATCH(dtype, k_attn_tokens_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (const char*)relu_mask, (char*)dx, K, P, TP, cch));
   return launch_status();
 }
 

@@ -35,7 +35,7 @@ def _L():
         L.cddmsl_avgpool2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
         L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_attn_tokens_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
-        L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 2 + [ci] * 5 + [vp]
+        L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
         L.cddmsl_gemm_nt_batched.argtypes = [vp] * 4 + [ci] * 7 + [c_long] * 3 + [ci, ci, vp]
         L.cddmsl_gemm_tn_batched.argtypes = [vp] * 3 + [ci] * 7 + [c_long] * 3 + [ci, ci, vp]
         L.cddmsl_relu_bwd.argtypes = [vp, vp, vp, c_long, ci, ci, vp]
@@ -332,13 +332,14 @@ def attn_tokens_fwd(x, pos, tp=None):
 
 
 @_timed("attn_tokens_bwd")
-def attn_tokens_bwd(dtok, P):
-    """dtok [K,TP,C] -> dx [K,P,C]"""
-    require_cuda(dtok)
+def attn_tokens_bwd(dtok, P, relu_mask=None):
+    """dtok [K,TP,C] -> dx [K,P,C], zeroed where relu_mask [K,P,C] <= 0"""
+    require_cuda(dtok, relu_mask)
     K, TP, C = dtok.shape
     assert dtok.is_contiguous()
+    assert relu_mask is None or (relu_mask.is_contiguous() and relu_mask.dtype == dtok.dtype and relu_mask.numel() == K * P * C)
     dx = torch.empty((K, P, C), device=dtok.device, dtype=dtok.dtype)
-    check(_L().cddmsl_attn_tokens_bwd(ptr(dtok), ptr(dx), K, P, TP, C, _dt(dtok), stream_ptr()), "cddmsl_attn_tokens_bwd")
+    check(_L().cddmsl_attn_tokens_bwd(ptr(dtok), ptr(relu_mask), ptr(dx), K, P, TP, C, _dt(dtok), stream_ptr()), "cddmsl_attn_tokens_bwd")
     return dx
 
 

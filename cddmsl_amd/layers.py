@@ -284,7 +284,8 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x):
 
 class ResStageFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, blocks):
+    def forward(ctx, x, anchor, blocks, out_grad_premasked=False):
+        ctx.out_grad_premasked = out_grad_premasked
         saved = [x]
         cur = x
         for bp in blocks:
@@ -299,21 +300,31 @@ class ResStageFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         blocks = ctx.blocks
         need_dx = ctx.needs_input_grad[0]
-        gs = hip.relu_bwd(g.contiguous(), saved[-1])   # mask by the stage output's ReLU
+        # mask by the stage output's ReLU -- unless the one consumer of the output has done it (res_stage_attnpool)
+        gs = g.contiguous() if ctx.out_grad_premasked else hip.relu_bwd(g.contiguous(), saved[-1])
         for i in range(len(blocks) - 1, -1, -1):
             x, o1, o2, p2, px = saved[5 * i: 5 * i + 5]
             gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0)
-        return gs, None, None
+        return gs, None, None, None
 
 
-def res_stage(x, blocks, frozen):
+def res_stage(x, blocks, frozen, out_grad_premasked=False):
     """Runs a residual stage.  Frozen stages (FREEZE_AT) and no-grad calls keep no activations."""
     if frozen or not torch.is_grad_enabled():
         cur = x
         for bp in blocks:
             cur, _ = _block_forward(cur, bp, False)
         return cur
-    return ResStageFn.apply(x, blocks[0].w[0], blocks)
+    return ResStageFn.apply(x, blocks[0].w[0], blocks, out_grad_premasked)
+
+
+def res_stage_attnpool(x, blocks, frozen, ap):
+    """layer4 -> AttentionPool2d (clip_roi_heads.py:160-165) as one composition: the pool's backward writes its input gradient
+    already masked by the stage's output ReLU (the map it pooled IS that output), so the stage skips its own relu_bwd pass
+    over the [K,7,7,2048] tensor.  Only valid because nothing else consumes the stage output -- which this function owns."""
+    fuse = not frozen and torch.is_grad_enabled()
+    y = res_stage(x, blocks, frozen, out_grad_premasked=fuse)
+    return AttnPoolFn.apply(y, None if ap.frozen else ap.q_w, ap, fuse)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -368,8 +379,10 @@ class AttnPoolFn(torch.autograd.Function):
     TP = 56
 
     @staticmethod
-    def forward(ctx, x, anchor, ap):
-        """x [K,h,w,C] NHWC T with h*w+1 == len(pos)  ->  [K, out_dim] f32"""
+    def forward(ctx, x, anchor, ap, premask_input_grad=False):
+        """x [K,h,w,C] NHWC T with h*w+1 == len(pos)  ->  [K, out_dim] f32.  ``premask_input_grad``: x is a ReLU output whose
+        producer expects dL/dx already zeroed where x <= 0 (res_stage_attnpool)."""
+        ctx.relu_src = x if premask_input_grad else None
         T = x.dtype
         K, h, w, C = x.shape
         P, TP, H = h * w, AttnPoolFn.TP, ap.heads
@@ -459,8 +472,8 @@ class AttnPoolFn(torch.autograd.Function):
         if train:
             gpos = hip.colsum(dtok.view(-1, C), period=TP)
             _grad_buf(ap.pos).add_(gpos[:P + 1])
-        dx = hip.attn_tokens_bwd(dtok, P).view(K, h, w, C) if ctx.needs_input_grad[0] else None
-        return dx, None, None
+        dx = hip.attn_tokens_bwd(dtok, P, ctx.relu_src).view(K, h, w, C) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None
 
 
 def attnpool(x, ap):

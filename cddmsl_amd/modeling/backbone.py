@@ -97,8 +97,12 @@ class ResStage(nn.Sequential):
             self._bp = (dev, [b.params() for b in self])
         return self._bp[1]
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, then_attnpool=None):
+        """``then_attnpool`` (an AttentionPool2d): returns the pooled embeddings of the stage output instead of the map --
+        the RoI head's layer4 -> attnpool composition with the ReLU backward fused (layers.res_stage_attnpool)."""
         frozen = self[0].frozen
+        if then_attnpool is not None:
+            return layers.res_stage_attnpool(x, self.block_params(), frozen, then_attnpool._params())
         return layers.res_stage(x, self.block_params(), frozen)
 
     def forward(self, x):

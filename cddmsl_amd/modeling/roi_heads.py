@@ -297,25 +297,28 @@ class CLIPRes5ROIHeads(nn.Module):
         self.storage["roi_head/num_bg_samples"] = sum(nbg) / max(len(nbg), 1)
         return out
 
-    def _shared_roi_transform(self, feat_nhwc, boxes, res5):
+    def _pooled_embeddings(self, feat_nhwc, boxes, res5, attnpool):
+        """RoIAlign -> layer4 -> attention pool (clip_roi_heads.py:160-165); with the package's own modules the last two run
+        as one composition (the stage's ReLU backward rides in the pool's backward)"""
         x = self.pooler.forward_nhwc(feat_nhwc, boxes)
-        return res5.forward_nhwc(x)
+        from .backbone import AttentionPool2d, ResStage
+        if isinstance(res5, ResStage) and isinstance(attnpool, AttentionPool2d):
+            return res5.forward_nhwc(x, then_attnpool=attnpool)
+        return attnpool(to_nchw(res5.forward_nhwc(x)))
 
     def forward_get_features(self, features_src, features_trgt, proposals, targets=None, res5=None, attnpool=None):
         """clip_roi_heads.py:117-132: the same boxes pooled from the source and the target map."""
         if self.training:
             assert targets
         boxes = [p.proposal_boxes for p in proposals]
-        fs = self._shared_roi_transform(to_nhwc(features_src[self.in_features[0]]), boxes, res5)
-        ft = self._shared_roi_transform(to_nhwc(features_trgt[self.in_features[0]]), boxes, res5)
-        return attnpool(to_nchw(fs)), attnpool(to_nchw(ft))
+        return (self._pooled_embeddings(to_nhwc(features_src[self.in_features[0]]), boxes, res5, attnpool),
+                self._pooled_embeddings(to_nhwc(features_trgt[self.in_features[0]]), boxes, res5, attnpool))
 
     def forward_get_features_paired(self, feat_cat_nhwc, num_images, proposals, res5, attnpool):
         """Same result as ``forward_get_features`` when source and target maps are stacked along the batch axis
         (images [0,B) = source, [B,2B) = target): ONE RoIAlign / layer4 / attention-pool pass over 2K regions."""
         boxes = [p.proposal_boxes for p in proposals]
-        x = self._shared_roi_transform(feat_cat_nhwc, boxes + boxes, res5)
-        att = attnpool(to_nchw(x))
+        att = self._pooled_embeddings(feat_cat_nhwc, boxes + boxes, res5, attnpool)
         k = att.shape[0] // 2
         return att[:k], att[k:]
 
@@ -326,8 +329,7 @@ class CLIPRes5ROIHeads(nn.Module):
             assert targets
             targets = [as_instances(t) for t in targets]
             proposals = self.label_and_sample_proposals(proposals, targets)
-        box_features = self._shared_roi_transform(to_nhwc(features[self.in_features[0]]), [p.proposal_boxes for p in proposals], res5)
-        att = attnpool(to_nchw(box_features))
+        att = self._pooled_embeddings(to_nhwc(features[self.in_features[0]]), [p.proposal_boxes for p in proposals], res5, attnpool)
         predictions = self.box_predictor(att)
         if self.training:
             return [], self.box_predictor.losses(predictions, proposals)
