@@ -147,6 +147,42 @@ class ConvFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None, None, (dy_in if ctx.needs_input_grad[9] else None)
 
 
+class FrozenMlpFn(torch.autograd.Function):
+    """y (f32) = residual + W2 relu(W1 x + b1) + b2 with frozen weights (the mapper's MlpTransformer, clipcap.py:39-56) as ONE
+    node: the ReLU backward rides in the epilogue of fc2's input-gradient GEMM (relu_mask = the saved hidden activations)
+    instead of a pass of its own over the [rows, hidden] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, pw1, b1, pw2, b2, residual):
+        T = x.dtype
+        w1, _ = pw1.get(T, need_dgrad=False)
+        w2, _ = pw2.get(T, need_dgrad=False)
+        M, K = x.shape
+        h = hip.conv_fwd(x.view(1, 1, M, K), w1, None, b1.detach(), relu=True)
+        y = hip.conv_fwd(h, w2, None, b2.detach(), residual.detach().view(1, 1, M, -1), out_f32=True)
+        ctx.pw = (pw1, pw2)
+        ctx.save_for_backward(h)
+        return y.view(M, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        T = h.dtype
+        M = h.shape[2]
+        g = dy.contiguous()
+        if g.dtype != T:
+            g = g.to(T)
+        _, w2d = ctx.pw[1].get(T, need_dgrad=True)
+        _, w1d = ctx.pw[0].get(T, need_dgrad=True)
+        dh = hip.conv_fwd(g.view(1, 1, M, -1), w2d, relu_mask=h)
+        dx = hip.conv_fwd(dh, w1d).view(M, -1) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, (dy if ctx.needs_input_grad[5] else None)
+
+
+def frozen_mlp(x2d, pw1, b1, pw2, b2, residual):
+    return FrozenMlpFn.apply(x2d.contiguous(), pw1, b1, pw2, b2, residual.contiguous())
+
+
 def conv(x, pw, bias=None, stride=1, pad=0, relu=False, out_f32=False, train_w=True, residual=None):
     """``residual`` (same shape as the output; f32 with ``out_f32`` on the bf16 path) is added in the GEMM epilogue."""
     anchor = pw.param if train_w else None

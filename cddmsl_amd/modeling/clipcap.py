@@ -31,6 +31,13 @@ class MlpTransformer(nn.Module):
         super().__init__()
         self.fc1, self.fc2 = _Lin(in_dim, h_dim), _Lin(h_dim, in_dim)
 
+    def forward(self, y, residual):
+        """y [M, in_dim] bf16, residual [M, in_dim] f32 -> residual + fc2(relu(fc1(y))) f32 (frozen weights)"""
+        for lin in (self.fc1, self.fc2):
+            if lin._pw is None or lin._pw.param is not lin.weight:
+                lin._pw = layers.PreparedWeight(lin.weight, None, frozen=True)
+        return layers.frozen_mlp(y, self.fc1._pw, self.fc1.bias, self.fc2._pw, self.fc2.bias, residual)
+
 
 class MultiHeadAttention(nn.Module):
     def __init__(self, dim, num_heads, bias=False):
@@ -92,7 +99,7 @@ class TransformerMapper(nn.Module):
                 o = layers.small_attention(a.to_queries(y, out_f32=False), a.to_keys_values(y, out_f32=False), t, H, a.scale)
                 h = a.project(o, residual=hs)                 # the f32 residual adds ride in the GEMM epilogues
                 y, hs = layers.layer_norm_skip(h, lyr.norm2.weight, lyr.norm2.bias, T)
-                h = lyr.mlp.fc2(lyr.mlp.fc1(y, relu=True, out_f32=False), residual=hs).view(n, t, d)
+                h = lyr.mlp(y, hs).view(n, t, d)              # fc2(relu(fc1 y)) + hs as one node (ReLU backward fused)
                 continue
             y = layers.layer_norm(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
             # exact-f32 parity path: the same arithmetic on torch ops (the fused kernel is bf16-only)
