@@ -85,6 +85,9 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* 
   RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
   if (dbg_grid && i == 0 && threadIdx.x == 0) { dbg_grid[2 * k] = g.gh; dbg_grid[2 * k + 1] = g.gw; }
   float count = (float)max(g.gh * g.gw, 1);
+  const int icount = max(g.gh * g.gw, 1);
+  const bool pow2 = (icount & (icount - 1)) == 0;
+  const float inv_count = 1.0f / count;
   const u32x4* xb = (const u32x4*)x + (long)g.b * H * W * cch;
   constexpr int VEC = Vec<T>::VEC;
   __shared__ int s_lo[2][ROI_MAXS], s_hi[2][ROI_MAXS];
@@ -144,8 +147,13 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* 
         }
       }
     }
+    if (pow2) {                                   // (x / 2^k == x * 2^-k exactly: skips 8 IEEE divisions per chunk)
 #pragma unroll
-    for (int q = 0; q < VEC; ++q) acc[q] /= count;
+      for (int q = 0; q < VEC; ++q) acc[q] *= inv_count;
+    } else {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) acc[q] /= count;
+    }
     ((u32x4*)y)[bin * cch + c] = Vec<T>::pack(acc);
   }
   }
