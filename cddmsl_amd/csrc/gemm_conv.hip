@@ -1606,6 +1606,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
         if (mo < p.M) {
           float v = acc[nt][g] * sc[nt] + bi[nt];
           if (p.relu) v = fmaxf(v, 0.f);
+          if (p.relu_mask && !(Mma<T>::load(p.relu_mask + ((long)mo * p.ldm + nt * 32 + r) * ES) > 0.f)) v = 0.f;
           Mma<T>::store(p.y + ((long)mo * p.ldy + nt * 32 + r) * ES, v);
         }
       }
@@ -2036,13 +2037,15 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   if (grid <= 0) return CDDMSL_OK;
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   // few-channel 3x3 layers (the CLIP stem): streaming register-weight kernel
-  if (!a.pool && a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.cpp == 1 || a.cpp == 4) && (a.Cout == 32 || a.Cout == 64) &&
-      !a.residual && !a.relu_mask && !a.out_f32 && g_batch == 1 && a.xrs == a.cpp && a.wrs == a.Kc) {
+  // (8 chunks per pixel = the 64 -> 64 layers of res2 in bf16, forward and -- with the ReLU mask -- input gradient)
+  if (!a.pool && a.KH == 3 && a.KW == 3 && a.pad == 1 && (a.cpp == 1 || a.cpp == 4 || (a.cpp == 8 && a.Cout == 64)) &&
+      (a.Cout == 32 || a.Cout == 64) && !a.residual && !a.out_f32 && g_batch == 1 && a.xrs == a.cpp && a.wrs == a.Kc) {
     g_last_kernel = 8;
     if (g_plan_only) return CDDMSL_OK;
     const int nb = 256 * 8;                       // 8 blocks of 4 waves per CU, grid-stride over 32-pixel tiles
     if (a.cpp == 1 && a.Cout == 32) hipLaunchKernelGGL((k_conv3x3_small<T, 1, 1>), dim3(nb), dim3(256), 0, st, a);
     else if (a.cpp == 1) hipLaunchKernelGGL((k_conv3x3_small<T, 1, 2>), dim3(nb), dim3(256), 0, st, a);
+    else if (a.cpp == 8) hipLaunchKernelGGL((k_conv3x3_small<T, 8, 2>), dim3(nb), dim3(256), 0, st, a);
     else if (a.Cout == 32) hipLaunchKernelGGL((k_conv3x3_small<T, 4, 1>), dim3(nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv3x3_small<T, 4, 2>), dim3(nb), dim3(256), 0, st, a);
     return launch_status();

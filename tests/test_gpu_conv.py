@@ -274,6 +274,30 @@ def test_pooled_residual_is_avgpool_backward(g256, dtype, tol, monkeypatch):
         assert (one.float() * 0 + hip.conv_fwd(x, w, residual=gp, residual_pooled=True).float() - ref).abs().max() < tol * ref.abs().max()
 
 
+def test_conv3x3_streaming_kernel_64_channels_and_relu_mask():
+    """The streaming 3x3 kernel at 8 chunks per pixel (the 64 -> 64 layers of res2, bf16): FrozenBN + ReLU forward, and the
+    input-gradient form (no affine, output zeroed where the ReLU mask is <= 0), ragged sizes, vs ATen fp32."""
+    from cddmsl_amd import hip
+    dtype, tol = torch.bfloat16, 2e-2
+    for (N, H, W) in ((2, 37, 53), (1, 200, 333)):
+        x = _rand((N, 64, H, W), 91).to(dtype).float()
+        w = (_rand((64, 64, 3, 3), 92) * (64 * 9) ** -0.5).to(dtype).float()
+        scale = torch.rand(64, generator=torch.Generator().manual_seed(93)) + 0.5
+        bias = _rand((64,), 94, 0.1)
+        msk = _rand((N, 64, H, W), 95).to(dtype).float()
+        conv = F.conv2d(x, w, padding=1)
+        wf, _ = hip.weight_prep(w.permute(0, 2, 3, 1).contiguous().cuda(), None, dtype, True, False)
+        y = hip.conv_fwd(_nhwc(x).cuda().to(dtype), wf, scale.cuda(), bias.cuda(), relu=True, pad=1)
+        assert hip._L().cddmsl_last_kernel() == 8
+        ref = F.relu(conv * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1))
+        assert (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max() < tol * ref.abs().max()
+        ym = hip.conv_fwd(_nhwc(x).cuda().to(dtype), wf, relu_mask=_nhwc(msk).cuda().to(dtype), pad=1)
+        assert hip._L().cddmsl_last_kernel() == 8
+        refm = conv * (msk > 0)
+        assert (ym.float().cpu().permute(0, 3, 1, 2) - refm).abs().max() < tol * refm.abs().max()
+        assert bool((ym.float().cpu().permute(0, 3, 1, 2)[msk <= 0] == 0).all())
+
+
 CASES_W256 = [
     # N, H, W, Cin, Cout, K, pad     (Cout % 256 == 0, KH*KW*Cin % 256 == 0, Cin % 64 == 0)
     (3, 14, 14, 256, 256, 3, 1),     # M = 588: ragged last reduction tile, 9 taps
