@@ -169,7 +169,7 @@ def main():
                                    f"(iter>10000: supervised + image-level + region-level), {args.batch} img/GPU "
                                    f"{args.height}x{args.width}, synthetic pixels + seeded random weights",
                        "global_batch": gb, "parallelism": f"dp{world}",
-                       "shared_source_pass": bool(tr.share_source_pass)},
+                       "shared_source_pass": bool(tr.share_source_pass), "fused_consistency_mapper_pass": bool(tr.fuse_consistency)},
             "roofline": {"bound": "mfma", "kernel": dom_name + " (implicit-GEMM conv / linear, forward + input-gradient)", "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_traffic.json)",

@@ -100,6 +100,8 @@ class SimpleTrainer:
         # run_step below issues every forward of a step before its single backward, on one batch object: the model may
         # evaluate backbone+RPN on the source images once for the supervised and the region-level branch (rcnn.py notes)
         self.share_source_pass = os.environ.get("CDDMSL_SHARE_SOURCE_PASS", "1") != "0"
+        # ... and run the two caption-consistency branches' rows through the frozen mapper and the projector together
+        self.fuse_consistency = os.environ.get("CDDMSL_FUSE_CONSISTENCY", "1") != "0"
 
     def compute_losses(self, data):
         """train_loop.py:331-365"""
@@ -108,7 +110,10 @@ class SimpleTrainer:
             self.model.share_source_pass = self.share_source_pass and self.iter > self.burn_in
         loss_dict = self.model(data)
         loss = {}
-        if self.iter > self.burn_in:
+        if self.iter > self.burn_in and self.fuse_consistency and hasattr(self.model, "forward_consistency"):
+            # the two consistency branches with ONE mapper / projector pass (same per-row results; rcnn.py forward_consistency)
+            loss.update(self.model(data, clipcap_model=self.clipcap_model, branch="caption_consistency_both", KD_regularization=kd))
+        elif self.iter > self.burn_in:
             loss.update(self.model(data, clipcap_model=self.clipcap_model, branch="caption_consistency", KD_regularization=kd))
             loss["cont_region_loss"] = self.model(data, clipcap_model=self.clipcap_model,
                                                   branch="caption_consistency_regionLevel", KD_regularization=kd)

@@ -145,6 +145,66 @@ class GeneralizedRCNN(nn.Module):
         fs, ft = gather_cat(p[:n].contiguous()), gather_cat(p[n:].contiguous())
         return layers.contrastive_loss(ft, fs), kd_loss
 
+    def _region_level_encode(self, batched_inputs):
+        """rcnn.py:422-470 up to the pooled region embeddings: (source regions, target regions), each [16 N, 1024]"""
+        # source and target images stacked on the batch axis: one backbone pass over 2N images, one RoI pass over
+        # 2x16N regions (identical per-sample results, half the kernel launches)
+        n = len(batched_inputs)
+        shared, self._shared = self._shared, None
+        if shared is not None and not (shared["inputs"] is batched_inputs and shared["step"] == layers._STEP[0]):
+            shared = None
+        imgs = ([] if shared else self._images(batched_inputs, "image")) + self._images(batched_inputs, "image_trgt")
+        sizes = [tuple(i.shape[-2:]) for i in self._images(batched_inputs, "image")] if shared is None else shared["sizes"]
+        assert sizes == [tuple(i.shape[-2:]) for i in imgs[-n:]], "a sample and its domain twin share one geometry"
+        Hp, Wp = max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes)
+        x = hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype)   # always /255: rcnn.py:201
+        f = self.backbone.forward_nhwc(x, want_res5=False)["res4"]
+        gts = [as_instances(x_["instances"]).to(self.device) for x_ in batched_inputs]
+        with torch.no_grad():
+            if shared is None:
+                props, _ = self.proposal_generator.forward_nhwc(sizes, f[:n].detach(), gts)
+            else:
+                f = torch.cat([shared["res4"], f])
+                self.proposal_generator.replay_sampling_draws(shared["counts"])
+                props = shared["proposals"]
+            sel_cpu = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image] for p in props]
+            # one pinned, non-blocking H2D of all picks (as rows of the concatenated proposal boxes) and ONE gather
+            offs = torch.tensor([0] + [len(p) for p in props]).cumsum(0)
+            pick = to_device_async(torch.cat([s_ + int(o) for s_, o in zip(sel_cpu, offs[:-1])]), self.device)
+            picked = torch.cat([p.proposal_boxes.tensor for p in props])[pick]
+            props = []
+            for size, b_ in zip(sizes, torch.split(picked, [len(s_) for s_ in sel_cpu])):
+                inst = Instances(tuple(size))
+                inst.proposal_boxes = Boxes(b_)
+                props.append(inst)
+        return self.roi_heads.forward_get_features_paired(f, n, props, self.backbone.layer4, self.backbone.attnpool)
+
+    def forward_consistency(self, batched_inputs, clipcap_model, KD_regularization=True):
+        """Both caption-consistency branches (rcnn.py:413-470) with ONE pass through the frozen mapper and ONE through the
+        projector: image embeddings [source; target] (2N rows), region embeddings (2 x 16N rows) and the teacher's source
+        embeddings (N rows, no gradient) are stacked on the batch axis.  Every mapper / projector operation is per row (or
+        per sequence), so each row's result is what its own branch would have computed; the image-level branch's ~150
+        launches over 2560-row operands disappear into the region-level ones.  Returns the three loss entries."""
+        both = self.preprocess_image_train(batched_inputs)
+        n = both.shape[0] // 2
+        enc_img = self._encode(self.backbone, both)                                   # [2N, 1024]
+        enc_teacher = None
+        if KD_regularization:
+            with torch.no_grad():
+                enc_teacher = self._encode(self.offline_backbone, both[:n])
+        rs, rt = self._region_level_encode(batched_inputs)
+        k = rs.shape[0]
+        parts = [enc_img, rs, rt] + ([enc_teacher] if enc_teacher is not None else [])
+        f = v2l(torch.cat(parts), clipcap_model)                                      # [2N + 2K (+ N), 768]
+        out = {}
+        if enc_teacher is not None:
+            out["kd_loss"] = torch.nn.functional.l1_loss(f[2 * n + 2 * k:].detach(), f[:n])
+        p = self.project(f[:2 * n + 2 * k])
+        out["cont_loss"] = layers.contrastive_loss(gather_cat(p[n:2 * n].contiguous()), gather_cat(p[:n].contiguous()))
+        e = p[2 * n:]
+        out["cont_region_loss"] = layers.contrastive_loss(gather_cat(e[:k].contiguous()), gather_cat(e[k:].contiguous()))
+        return out
+
     # ------------------------------------------------------------------ forward
     # ------------------------------------------------------------------ inference (rcnn.py:690-784)
     @torch.no_grad()
@@ -177,40 +237,12 @@ class GeneralizedRCNN(nn.Module):
             cont, kd = self.v2l_contrastive(both, clipcap_model, KD_regularization)
             return {"cont_loss": cont, "kd_loss": kd} if kd is not None else {"cont_loss": cont}
         if branch == "caption_consistency_regionLevel":         # rcnn.py:422-470
-            # source and target images stacked on the batch axis: one backbone pass over 2N images, one RoI pass over
-            # 2x16N regions (identical per-sample results, half the kernel launches)
-            n = len(batched_inputs)
-            shared, self._shared = self._shared, None
-            if shared is not None and not (shared["inputs"] is batched_inputs and shared["step"] == layers._STEP[0]):
-                shared = None
-            imgs = ([] if shared else self._images(batched_inputs, "image")) + self._images(batched_inputs, "image_trgt")
-            sizes = [tuple(i.shape[-2:]) for i in self._images(batched_inputs, "image")] if shared is None else shared["sizes"]
-            assert sizes == [tuple(i.shape[-2:]) for i in imgs[-n:]], "a sample and its domain twin share one geometry"
-            Hp, Wp = max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes)
-            x = hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype)   # always /255: rcnn.py:201
-            f = self.backbone.forward_nhwc(x, want_res5=False)["res4"]
-            gts = [as_instances(x_["instances"]).to(self.device) for x_ in batched_inputs]
-            with torch.no_grad():
-                if shared is None:
-                    props, _ = self.proposal_generator.forward_nhwc(sizes, f[:n].detach(), gts)
-                else:
-                    f = torch.cat([shared["res4"], f])
-                    self.proposal_generator.replay_sampling_draws(shared["counts"])
-                    props = shared["proposals"]
-                sel_cpu = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image] for p in props]
-                # one pinned, non-blocking H2D of all picks (as rows of the concatenated proposal boxes) and ONE gather
-                offs = torch.tensor([0] + [len(p) for p in props]).cumsum(0)
-                pick = to_device_async(torch.cat([s_ + int(o) for s_, o in zip(sel_cpu, offs[:-1])]), self.device)
-                picked = torch.cat([p.proposal_boxes.tensor for p in props])[pick]
-                props = []
-                for size, b_ in zip(sizes, torch.split(picked, [len(s_) for s_ in sel_cpu])):
-                    inst = Instances(tuple(size))
-                    inst.proposal_boxes = Boxes(b_)
-                    props.append(inst)
-            rs, rt = self.roi_heads.forward_get_features_paired(f, n, props, self.backbone.layer4, self.backbone.attnpool)
+            rs, rt = self._region_level_encode(batched_inputs)
             e = self.project(v2l(torch.cat([rs, rt]), clipcap_model))
             k = rs.shape[0]
             return layers.contrastive_loss(gather_cat(e[:k].contiguous()), gather_cat(e[k:].contiguous()))
+        if branch == "caption_consistency_both":
+            return self.forward_consistency(batched_inputs, clipcap_model, KD_regularization)
         # supervised: rcnn.py:592-623
         images, sizes = self.preprocess_image(batched_inputs, "image")
         gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]

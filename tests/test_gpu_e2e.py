@@ -64,6 +64,7 @@ def test_step_losses_and_grads_match_oracle(kd, share, gemm256, monkeypatch):
     tr = SimpleTrainer(model, iter([batch]), opt, cfg, clipcap_model=mapper, metrics_period=0)
     tr.iter = 20000   # past burn-in: all three branches live
     tr.share_source_pass = share
+    tr.fuse_consistency = share       # (share=True also runs both consistency branches through ONE mapper / projector pass)
     tr.buckets.zero()
     ld = tr.compute_losses(batch)
     sum(ld.values()).backward()
