@@ -63,10 +63,13 @@ __global__ void k_nms_mask(const float* boxes, unsigned long long* mask, int n, 
   int img = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;  // only j > i matters
   const float* b = boxes + (long)img * n * 4;
-  __shared__ float cbx[64 * 4];
+  __shared__ float cbx[64 * 4], car[64];
   int t = threadIdx.x;
   int cj = cb * 64 + t;
-  if (cj < n) { cbx[4 * t] = b[4 * cj]; cbx[4 * t + 1] = b[4 * cj + 1]; cbx[4 * t + 2] = b[4 * cj + 2]; cbx[4 * t + 3] = b[4 * cj + 3]; }
+  if (cj < n) {
+    cbx[4 * t] = b[4 * cj]; cbx[4 * t + 1] = b[4 * cj + 1]; cbx[4 * t + 2] = b[4 * cj + 2]; cbx[4 * t + 3] = b[4 * cj + 3];
+    car[t] = (b[4 * cj + 2] - b[4 * cj]) * (b[4 * cj + 3] - b[4 * cj + 1]);
+  }
   __syncthreads();
   int i = rb * 64 + t;
   if (i >= n) return;
@@ -79,9 +82,14 @@ __global__ void k_nms_mask(const float* boxes, unsigned long long* mask, int n, 
     float xx2 = fminf(x1, cbx[4 * j + 2]), yy2 = fminf(y1, cbx[4 * j + 3]);
     float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
     float inter = w * h;
-    float aj = (cbx[4 * j + 2] - cbx[4 * j]) * (cbx[4 * j + 3] - cbx[4 * j + 1]);
-    float iou = inter / (ai + aj - inter);
-    if (iou > thr) bits |= 1ull << j;
+    float u = ai + car[j] - inter;
+    // inter / u > thr decided without the division: r = inter - thr*u is exact in sign (one fma).  The rounded quotient can
+    // only disagree with the real one when the real quotient lies within half an ulp above thr, i.e. 0 < r < ~6e-8 u: those
+    // (rare) lanes take the division, so the bit is the one `inter / u > thr` gives in every case.
+    float r = fmaf(-thr, u, inter);
+    bool over = r > 0.f && u > 0.f;                 // (u <= 0: degenerate boxes, the quotient is NaN or <= 0)
+    if (over && r < 2.5e-7f * u) over = inter / u > thr;
+    if (over) bits |= 1ull << j;
   }
   mask[((long)img * n + i) * nw + cb] = bits;
 }
