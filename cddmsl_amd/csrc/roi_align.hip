@@ -78,12 +78,17 @@ __device__ __forceinline__ bool axis_tap(float v, int L, int& lo, int& hi, float
 // arithmetic (~50 vector instructions per sample) was most of the kernel (VALU-bound at 3x its HBM time).  Same tap
 // expressions, same accumulation order: bit-identical output.
 constexpr int ROI_MAXS = 256;     // samples per axis held in LDS (adaptive sampling grids beyond that take the inline path)
-template <typename T>
-__global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* dbg_grid, int N, int H, int W, int cch,
+// RP = bin rows (and columns) per step: 1, or 2 when the 2x2-average-pooled map is written as well (yp): the first block of the
+// RoI head's layer4 pools its input for the downsample path (clip_backbone.py:45-52), and reading the 3.3 GB map back just
+// for that costs more than computing four neighbouring bins in one thread.  The pooled value is formed from the four ROUNDED
+// outputs in avgpool2_fwd's order, so it is bit-identical to pooling the stored map.
+template <typename T, int RP>
+__global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char* yp, int* dbg_grid, int N, int H, int W, int cch,
                                 int ph, int pw, float scale, int sampling_ratio, int aligned) {
-  const int i = blockIdx.x % ph, k = blockIdx.x / ph;
+  const int nrb = ph / RP;
+  const int i0 = (blockIdx.x % nrb) * RP, k = blockIdx.x / nrb;
   RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
-  if (dbg_grid && i == 0 && threadIdx.x == 0) { dbg_grid[2 * k] = g.gh; dbg_grid[2 * k + 1] = g.gw; }
+  if (dbg_grid && i0 == 0 && threadIdx.x == 0) { dbg_grid[2 * k] = g.gh; dbg_grid[2 * k + 1] = g.gw; }
   float count = (float)max(g.gh * g.gw, 1);
   const int icount = max(g.gh * g.gw, 1);
   const bool pow2 = (icount & (icount - 1)) == 0;
@@ -92,13 +97,14 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* 
   constexpr int VEC = Vec<T>::VEC;
   __shared__ int s_lo[2][ROI_MAXS], s_hi[2][ROI_MAXS];
   __shared__ float s_wl[2][ROI_MAXS], s_wh[2][ROI_MAXS];
-  const int ny = g.gh, nx = pw * g.gw;
+  const int ny = RP * g.gh, nx = pw * g.gw;
   const bool tabled = ny <= ROI_MAXS && nx <= ROI_MAXS;
   if (tabled) {
     for (int s = threadIdx.x; s < ny + nx; s += blockDim.x) {
       int lo = -1, hi = -1; float wl = 0.f, wh = 0.f;
       if (s < ny) {
-        const float yy = g.y0 + (float)i * g.bh + ((float)s + 0.5f) * g.bh / (float)g.gh;
+        const int rr = s / g.gh, iy = s - rr * g.gh;
+        const float yy = g.y0 + (float)(i0 + rr) * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
         if (!axis_tap(yy, H, lo, hi, wl, wh)) lo = -1;
         s_lo[0][s] = lo; s_hi[0][s] = hi; s_wl[0][s] = wl; s_wh[0][s] = wh;
       } else {
@@ -110,17 +116,23 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* 
     }
     __syncthreads();
   }
-  for (int j = 0; j < pw; ++j) {
-  const long bin = ((long)k * ph + i) * pw + j;
+  for (int j0 = 0; j0 < pw; j0 += RP) {
   for (int c = threadIdx.x; c < cch; c += blockDim.x) {
+    u32x4 outp[RP][RP];
+#pragma unroll
+    for (int rr = 0; rr < RP; ++rr)
+#pragma unroll
+    for (int cc = 0; cc < RP; ++cc) {
+    const int i = i0 + rr, j = j0 + cc;
+    const long bin = ((long)k * ph + i) * pw + j;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (g.b >= 0 && g.b < N) {
       for (int iy = 0; iy < g.gh; ++iy) {
         int yl, yh; float wyl, wyh;
         if (tabled) {
-          yl = s_lo[0][iy];
+          yl = s_lo[0][rr * g.gh + iy];
           if (yl < 0) continue;
-          yh = s_hi[0][iy]; wyl = s_wl[0][iy]; wyh = s_wh[0][iy];
+          yh = s_hi[0][rr * g.gh + iy]; wyl = s_wl[0][rr * g.gh + iy]; wyh = s_wh[0][rr * g.gh + iy];
         } else {
           float yy = g.y0 + (float)i * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
           if (!axis_tap(yy, H, yl, yh, wyl, wyh)) continue;
@@ -154,7 +166,17 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, int* 
 #pragma unroll
       for (int q = 0; q < VEC; ++q) acc[q] /= count;
     }
-    ((u32x4*)y)[bin * cch + c] = Vec<T>::pack(acc);
+    outp[rr][cc] = Vec<T>::pack(acc);
+    ((u32x4*)y)[bin * cch + c] = outp[rr][cc];
+    }
+    if (RP == 2) {
+      float a0[8], a1[8], a2[8], a3[8], o[8];
+      Vec<T>::unpack(outp[0][0], a0); Vec<T>::unpack(outp[0][RP - 1], a1);
+      Vec<T>::unpack(outp[RP - 1][0], a2); Vec<T>::unpack(outp[RP - 1][RP - 1], a3);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) o[q] = ((a0[q] + a1[q]) + (a2[q] + a3[q])) * 0.25f;
+      ((u32x4*)yp)[(((long)k * (ph / 2) + i0 / 2) * (pw / 2) + j0 / 2) * cch + c] = Vec<T>::pack(o);
+    }
   }
   }
 }
@@ -298,20 +320,23 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(const char* dy, const flo
 
 }  // namespace
 
-extern "C" int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, int* dbg_grid, int N, int C, int H,
-                                        int W, int K, int ph, int pw, float spatial_scale, int sampling_ratio,
+extern "C" int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, void* y_pooled, int* dbg_grid, int N, int C,
+                                        int H, int W, int K, int ph, int pw, float spatial_scale, int sampling_ratio,
                                         int aligned, int dtype, void* stream) {
   int es = dtype == 0 ? 2 : 4;
   if ((dtype != 0 && dtype != 1) || (C * es) % 16 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || K < 0 || N < 0)
     return CDDMSL_ERR_ARG;
   if (K == 0) return CDDMSL_OK;   // empty inputs return correctly-shaped empties (poolers.py:221-224)
   int cch = C * es / 16;
-  long grid = (long)K * ph;
+  if (y_pooled && ((ph & 1) || (pw & 1))) return CDDMSL_ERR_ARG;      // the pooled copy needs whole 2x2 groups of bins
+  long grid = (long)K * (y_pooled ? ph / 2 : ph);
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   int threads = cch >= 256 ? 256 : ((cch + 63) / 64) * 64;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == 0) k_roi_align_fwd<__bf16><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned);
-  else k_roi_align_fwd<float><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned);
+#define CDDMSL_RAF(TT, RPP) k_roi_align_fwd<TT, RPP><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, (char*)y_pooled, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned)
+  if (dtype == 0) { if (y_pooled) CDDMSL_RAF(__bf16, 2); else CDDMSL_RAF(__bf16, 1); }
+  else { if (y_pooled) CDDMSL_RAF(float, 2); else CDDMSL_RAF(float, 1); }
+#undef CDDMSL_RAF
   return launch_status();
 }
 

@@ -41,7 +41,7 @@ def _L():
         L.cddmsl_relu_bwd.argtypes = [vp, vp, vp, c_long, ci, ci, vp]
         L.cddmsl_colsum.argtypes = [vp, vp, c_long, ci, ci, ci, vp]
         L.cddmsl_sgd_clip_step.argtypes = [vp] * 4 + [ci, vp] + [cf] * 4 + [ci, vp]
-        L.cddmsl_roi_align_forward.argtypes = [vp] * 4 + [ci] * 7 + [cf, ci, ci, ci, vp]
+        L.cddmsl_roi_align_forward.argtypes = [vp] * 5 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_roi_align_backward.argtypes = [vp] * 7 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_anchors.argtypes = [vp, vp, ci, ci, ci, cf, cf, vp]
         L.cddmsl_sort_desc.argtypes = [vp] * 5 + [ci, ci, vp, vp, vp]
@@ -423,16 +423,18 @@ def sgd_clip_step(params, grads, moms, norm_ws, lr, momentum, wd, clip, first_st
 
 # ------------------------------------------------------------------------------------------------ RoIAlign
 @_timed("roi_align_forward")
-def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, dbg_grid=None):
-    """x NHWC [N,H,W,C]; rois [K,5] f32 (batch_idx,x0,y0,x1,y1) -> [K,ph,pw,C]  (layers/roi_align.py:49-65)."""
+def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, dbg_grid=None, with_pooled=False):
+    """x NHWC [N,H,W,C]; rois [K,5] f32 (batch_idx,x0,y0,x1,y1) -> [K,ph,pw,C]  (layers/roi_align.py:49-65).
+    ``with_pooled``: also returns AvgPool2d(2) of the result [K,ph/2,pw/2,C] (bit-identical to avgpool2_fwd of it)."""
     require_cuda(x, rois)
     assert rois.dim() == 2 and rois.size(1) == 5 and rois.dtype == torch.float32 and rois.is_contiguous()
     N, H, W, C = x.shape
     K = rois.shape[0]
     y = torch.empty((K, ph, pw, C), device=x.device, dtype=x.dtype)
-    check(_L().cddmsl_roi_align_forward(ptr(x), ptr(rois), ptr(y), ptr(dbg_grid), N, C, H, W, K, ph, pw, spatial_scale,
+    yp = torch.empty((K, ph // 2, pw // 2, C), device=x.device, dtype=x.dtype) if with_pooled else None
+    check(_L().cddmsl_roi_align_forward(ptr(x), ptr(rois), ptr(y), ptr(yp), ptr(dbg_grid), N, C, H, W, K, ph, pw, spatial_scale,
                                          sampling_ratio, int(aligned), _dt(x), stream_ptr()), "cddmsl_roi_align_forward")
-    return y
+    return (y, yp) if with_pooled else y
 
 
 @_timed("roi_align_backward")

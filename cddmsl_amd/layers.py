@@ -257,7 +257,7 @@ class BlockParams:
         self.pw = tuple(None if w is None else PreparedWeight(w, b[0], frozen) for w, b in zip(self.w, self.bn))
 
 
-def _block_forward(x, bp, save):
+def _block_forward(x, bp, save, px_given=None):
     """Bottleneck forward (clip_backbone.py:57-70).  AvgPool2d(stride) runs as its own HBM-bound kernel: fusing it into
     the GEMM A-loader (kernel option pool=1, kept and tested) halves the MFMA rate of this kernel structure."""
     T = x.dtype
@@ -269,7 +269,10 @@ def _block_forward(x, bp, save):
     o1 = hip.conv_fwd(x, w1, s1, b1, relu=True)
     o2 = hip.conv_fwd(o1, w2, s2, b2, relu=True, pad=1)
     p2 = hip.avgpool2_fwd(o2) if pool else o2
-    px = hip.avgpool2_fwd(x) if pool else x
+    if pool and px_given is not None and tuple(px_given.shape) == (x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]):
+        px = px_given                              # the producer of x pooled it on the way (roi_align with_pooled)
+    else:
+        px = hip.avgpool2_fwd(x) if pool else x
     if bp.pw[3] is not None:
         wd, _ = bp.pw[3].get(T, False)
         idn = hip.conv_fwd(px, wd, bnd[0], bnd[1])
@@ -320,12 +323,12 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x):
 
 class ResStageFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, blocks, out_grad_premasked=False):
+    def forward(ctx, x, anchor, blocks, out_grad_premasked=False, px0=None):
         ctx.out_grad_premasked = out_grad_premasked
         saved = [x]
         cur = x
-        for bp in blocks:
-            cur, mids = _block_forward(cur, bp, True)
+        for bi, bp in enumerate(blocks):
+            cur, mids = _block_forward(cur, bp, True, px0 if bi == 0 else None)
             saved += [mids[0], mids[1], mids[2], mids[3], cur]
         ctx.blocks = blocks
         ctx.save_for_backward(*saved)
@@ -341,17 +344,18 @@ class ResStageFn(torch.autograd.Function):
         for i in range(len(blocks) - 1, -1, -1):
             x, o1, o2, p2, px = saved[5 * i: 5 * i + 5]
             gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0)
-        return gs, None, None, None
+        return gs, None, None, None, None
 
 
 def res_stage(x, blocks, frozen, out_grad_premasked=False):
     """Runs a residual stage.  Frozen stages (FREEZE_AT) and no-grad calls keep no activations."""
+    px0 = getattr(x, "_pooled2", None)               # 2x2-pooled copy of x supplied by its producer (roi_align)
     if frozen or not torch.is_grad_enabled():
         cur = x
-        for bp in blocks:
-            cur, _ = _block_forward(cur, bp, False)
+        for bi, bp in enumerate(blocks):
+            cur, _ = _block_forward(cur, bp, False, px0 if bi == 0 else None)
         return cur
-    return ResStageFn.apply(x, blocks[0].w[0], blocks, out_grad_premasked)
+    return ResStageFn.apply(x, blocks[0].w[0], blocks, out_grad_premasked, px0)
 
 
 def res_stage_attnpool(x, blocks, frozen, ap):
@@ -368,22 +372,31 @@ def res_stage_attnpool(x, blocks, frozen, ap):
 # ------------------------------------------------------------------------------------------------
 class RoIAlignFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rois, roi_start, out_size, scale, sampling_ratio, aligned):
-        y = hip.roi_align_forward(x, rois, out_size, out_size, scale, sampling_ratio, aligned)
+    def forward(ctx, x, rois, roi_start, out_size, scale, sampling_ratio, aligned, with_pooled=False):
+        out = hip.roi_align_forward(x, rois, out_size, out_size, scale, sampling_ratio, aligned, with_pooled=with_pooled)
         ctx.save_for_backward(rois, roi_start)
         ctx.meta = (tuple(x.shape), scale, sampling_ratio, aligned)
-        return y
+        if with_pooled:
+            ctx.mark_non_differentiable(out[1])      # a by-product: the consumer (ResStageFn) differentiates through y alone
+            return out
+        return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         rois, roi_start = ctx.saved_tensors
         shape, scale, sr, aligned = ctx.meta
         dx = hip.roi_align_backward(dy.contiguous(), rois, roi_start, shape, scale, sr, aligned)
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
-def roi_align(x, rois, roi_start, out_size, scale, sampling_ratio, aligned=True):
+def roi_align(x, rois, roi_start, out_size, scale, sampling_ratio, aligned=True, with_pooled=False):
+    """``with_pooled`` (even out_size): the result carries its 2x2-average-pooled copy as ``y._pooled2`` -- the first block of
+    a stride-2 residual stage picks it up instead of pooling the map again (res_stage)."""
     assert rois.dim() == 2 and rois.size(1) == 5  # layers/roi_align.py:55
+    if with_pooled and out_size % 2 == 0:
+        y, yp = RoIAlignFn.apply(x, rois, roi_start, out_size, scale, sampling_ratio, aligned, True)
+        y._pooled2 = yp
+        return y
     return RoIAlignFn.apply(x, rois, roi_start, out_size, scale, sampling_ratio, aligned)
 
 

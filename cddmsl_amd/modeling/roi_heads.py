@@ -30,14 +30,15 @@ class ROIPooler(nn.Module):
         assert len(scales) == 1 and pooler_type == "ROIAlignV2"
         self.output_size, self.scale, self.sampling_ratio = output_size, scales[0], sampling_ratio
 
-    def forward_nhwc(self, feat, box_lists: List[Boxes]):
+    def forward_nhwc(self, feat, box_lists: List[Boxes], with_pooled=False):
+        """``with_pooled``: the crops carry their 2x2-average-pooled copy for the stride-2 stage that follows (layers.roi_align)"""
         dev = feat.device
         counts = [len(b) for b in box_lists]
         # convert_boxes_to_pooler_format poolers.py:68-95: rois grouped by image, (batch_idx, x0, y0, x1, y1)
         bidx = to_device_async(torch.repeat_interleave(torch.arange(len(counts), dtype=torch.float32), torch.tensor(counts)), dev)
         rois = torch.cat([bidx[:, None], torch.cat([b.tensor.float() for b in box_lists])], dim=1).contiguous()
         start = to_device_async(torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32), dev)
-        return layers.roi_align(feat, rois, start, self.output_size, self.scale, self.sampling_ratio, True)
+        return layers.roi_align(feat, rois, start, self.output_size, self.scale, self.sampling_ratio, True, with_pooled=with_pooled)
 
     def forward(self, x, box_lists):
         return to_nchw(self.forward_nhwc(to_nhwc(x[0]), box_lists))
@@ -300,9 +301,11 @@ class CLIPRes5ROIHeads(nn.Module):
     def _pooled_embeddings(self, feat_nhwc, boxes, res5, attnpool):
         """RoIAlign -> layer4 -> attention pool (clip_roi_heads.py:160-165); with the package's own modules the last two run
         as one composition (the stage's ReLU backward rides in the pool's backward)"""
-        x = self.pooler.forward_nhwc(feat_nhwc, boxes)
         from .backbone import AttentionPool2d, ResStage
-        if isinstance(res5, ResStage) and isinstance(attnpool, AttentionPool2d):
+        fused = isinstance(res5, ResStage) and isinstance(attnpool, AttentionPool2d)
+        # (CLIP's layer4 is stride 2 with an AvgPool2d on the downsample path: RoIAlign hands it the pooled crops as well)
+        x = self.pooler.forward_nhwc(feat_nhwc, boxes, with_pooled=fused and res5[0].stride > 1)
+        if fused:
             return res5.forward_nhwc(x, then_attnpool=attnpool)
         return attnpool(to_nchw(res5.forward_nhwc(x)))
 

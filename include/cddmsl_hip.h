@@ -67,8 +67,10 @@ int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_
 int cddmsl_weight_prep_multi(const long long* table, int count, int dtype, void* stream);
 
 /* ---- RoIAlign  (layers/roi_align.py:49-65 -> torchvision.ops.roi_align; modeling/poolers.py:190-229) --------- */
-int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, int* dbg_grid, int N, int C, int H, int W, int K,
-                             int ph, int pw, float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
+/* y_pooled (nullable, [K][ph/2][pw/2][C], ph and pw even): AvgPool2d(2) of y, formed from the rounded outputs in the pooling
+ * kernel's order -- what the first Bottleneck of the RoI head's layer4 reads on its downsample path (clip_backbone.py:45-52) */
+int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, void* y_pooled, int* dbg_grid, int N, int C, int H, int W,
+                             int K, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
 int cddmsl_roi_align_backward(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay, float* ws_ax,
                               int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw, float spatial_scale,
                               int sampling_ratio, int aligned, int dtype, void* stream);

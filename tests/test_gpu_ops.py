@@ -140,6 +140,25 @@ def test_anchors_iou_match_bitexact():
     assert (me == 0).all() and (le == 0).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roi_align_pooled_byproduct_is_avgpool_of_the_result(dtype):
+    """roi_align_forward(with_pooled=True): the crops are the same as without it, and the second output is bit-identical to
+    avgpool2_fwd of the crops (it is formed from the rounded outputs in the pooling kernel's order)."""
+    from cddmsl_amd import hip
+    g = torch.Generator().manual_seed(17)
+    N, H, W, C, K = 2, 25, 31, 64, 37
+    x = torch.randn(N, H, W, C, generator=g).to(dtype).cuda()
+    b = torch.rand(K, 4, generator=g)
+    x0, y0 = b[:, 0] * 300, b[:, 1] * 250
+    rois = torch.stack([torch.randint(0, N, (K,), generator=g).float(), x0, y0, x0 + 8 + b[:, 2] * 200, y0 + 8 + b[:, 3] * 150], dim=1)
+    rois = rois[rois[:, 0].argsort(stable=True)].contiguous().cuda()
+    for sr in (0, 2):
+        y = hip.roi_align_forward(x, rois, 14, 14, 1.0 / 16, sr, True)
+        y2, yp = hip.roi_align_forward(x, rois, 14, 14, 1.0 / 16, sr, True, with_pooled=True)
+        assert torch.equal(y, y2)
+        assert torch.equal(yp, hip.avgpool2_fwd(y))
+
+
 def test_sort_decode_nms_bitexact():
     from cddmsl_amd import hip
     from oracle import ops as oo
