@@ -159,6 +159,29 @@ def test_roi_align_pooled_byproduct_is_avgpool_of_the_result(dtype):
         assert torch.equal(yp, hip.avgpool2_fwd(y))
 
 
+def test_frozen_mlp_node_matches_torch():
+    """layers.frozen_mlp (the mapper's MlpTransformer as one node: f32 residual in fc2's epilogue, ReLU backward in fc2's
+    input-gradient epilogue) vs fp32 torch on the same bf16-rounded operands: output, input gradient, residual gradient."""
+    from cddmsl_amd import layers
+    g = torch.Generator().manual_seed(23)
+    M, D, Hd = 700, 768, 1536
+    w1 = torch.nn.Parameter((torch.randn(Hd, D, generator=g) * D ** -0.5).cuda())
+    w2 = torch.nn.Parameter((torch.randn(D, Hd, generator=g) * Hd ** -0.5).cuda())
+    b1, b2 = (torch.randn(Hd, generator=g) * 0.1).cuda(), (torch.randn(D, generator=g) * 0.1).cuda()
+    x = torch.randn(M, D, generator=g).cuda().bfloat16().requires_grad_(True)
+    res = torch.randn(M, D, generator=g).cuda().requires_grad_(True)
+    y = layers.frozen_mlp(x, layers.PreparedWeight(w1, None, frozen=True), b1, layers.PreparedWeight(w2, None, frozen=True), b2, res)
+    gy = torch.randn(M, D, generator=g).cuda()
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    h = torch.relu(xr @ w1.detach().bfloat16().float().t() + b1).bfloat16().float()
+    yr = h @ w2.detach().bfloat16().float().t() + b2 + res.detach()
+    yr.backward(gy.bfloat16().float())
+    assert y.dtype == torch.float32 and (y - yr).abs().max() < 2e-2 * yr.abs().max()
+    assert torch.equal(res.grad, gy)
+    assert (x.grad.float() - xr.grad).abs().max() < 3e-2 * xr.grad.abs().max()
+
+
 def test_sort_decode_nms_bitexact():
     from cddmsl_amd import hip
     from oracle import ops as oo
