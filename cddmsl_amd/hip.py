@@ -690,6 +690,34 @@ def attn_small_fwd(q, kv, t, heads, scale):
 
 
 @_timed("attn_small")
+def attn_small_fwd_qkv(qkv, t, heads, scale):
+    """qkv [n*t, 3d] (queries | keys | values: ONE projection GEMM's output), bf16 -> o [n*t, d]"""
+    require_cuda(qkv)
+    assert qkv.dim() == 2 and qkv.is_contiguous() and qkv.dtype == torch.bfloat16 and qkv.shape[1] % 3 == 0 and qkv.shape[0] % t == 0
+    R, d = qkv.shape[0], qkv.shape[1] // 3
+    o = torch.empty((R, d), device=qkv.device, dtype=qkv.dtype)
+    base = qkv.data_ptr()
+    check(_L().cddmsl_attn_small_fwd(c_void_p(base), c_void_p(base + d * 2), c_void_p(base + 4 * d), ptr(o), R // t, t, heads, d // heads,
+                                     3 * d, 3 * d, 3 * d, d, float(scale), 0, stream_ptr()), "cddmsl_attn_small_fwd")
+    return o
+
+
+@_timed("attn_small")
+def attn_small_bwd_qkv(qkv, do, t, heads, scale):
+    """-> dqkv [n*t, 3d] bf16 (the three gradients side by side: ONE input-gradient GEMM follows)"""
+    require_cuda(qkv, do)
+    R, d = qkv.shape[0], qkv.shape[1] // 3
+    do = do.contiguous()
+    assert do.shape == (R, d) and do.dtype == qkv.dtype
+    dqkv = torch.empty_like(qkv)
+    base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+    check(_L().cddmsl_attn_small_bwd(c_void_p(base), c_void_p(base + d * 2), c_void_p(base + 4 * d), ptr(do), c_void_p(gbase),
+                                     c_void_p(gbase + d * 2), c_void_p(gbase + 4 * d), R // t, t, heads, d // heads, 3 * d, 3 * d, 3 * d, d,
+                                     float(scale), 0, stream_ptr()), "cddmsl_attn_small_bwd")
+    return dqkv
+
+
+@_timed("attn_small")
 def attn_small_bwd(q, kv, do, t, heads, scale):
     """-> (dq [n*t, d], dkv [n*t, 2d]) bf16"""
     require_cuda(q, kv, do)

@@ -687,3 +687,24 @@ class SmallAttnFn(torch.autograd.Function):
 
 def small_attention(q, kv, t, heads, scale):
     return SmallAttnFn.apply(q, kv, t, heads, scale)
+
+
+class SmallAttnQkvFn(torch.autograd.Function):
+    """The same on the output of ONE fused q|k|v projection [n*t, 3d]: the backward hands back one [n*t, 3d] gradient, so
+    the projection's input gradient is one GEMM and no add of two partial gradients."""
+
+    @staticmethod
+    def forward(ctx, qkv, t, heads, scale):
+        ctx.save_for_backward(qkv)
+        ctx.cfg = (t, heads, scale)
+        return hip.attn_small_fwd_qkv(qkv, t, heads, scale)
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        t, heads, scale = ctx.cfg
+        return hip.attn_small_bwd_qkv(qkv, do, t, heads, scale), None, None, None
+
+
+def small_attention_qkv(qkv, t, heads, scale):
+    return SmallAttnQkvFn.apply(qkv, t, heads, scale)

@@ -47,6 +47,16 @@ class MultiHeadAttention(nn.Module):
         self.to_queries = _Lin(dim, dim, bias)
         self.to_keys_values = _Lin(dim, dim * 2, bias)
         self.project = _Lin(dim, dim)
+        self._qkv = None          # (key, fused frozen weight [3 dim, dim], its PreparedWeight)
+
+    def qkv_weight(self):
+        """to_queries and to_keys_values (bias-free, frozen) as ONE [3 dim, dim] GEMM operand, rebuilt when either changes"""
+        wq, wkv = self.to_queries.weight, self.to_keys_values.weight
+        key = (wq.data_ptr(), wq._version, wkv.data_ptr(), wkv._version)
+        if self._qkv is None or self._qkv[0] != key:
+            w = torch.nn.Parameter(torch.cat([wq.detach(), wkv.detach()], dim=0), requires_grad=False)
+            self._qkv = (key, w, layers.PreparedWeight(w, None, frozen=True))
+        return self._qkv[2]
 
 
 class TransformerLayer(nn.Module):
@@ -96,7 +106,11 @@ class TransformerMapper(nn.Module):
                 # throughput path: projections emit bf16, one fused attention kernel per direction, heads stay column blocks;
                 # LayerNorm hands back its input for the residual add so that the backward accumulates in one kernel
                 y, hs = layers.layer_norm_skip(h.view(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)
-                o = layers.small_attention(a.to_queries(y, out_f32=False), a.to_keys_values(y, out_f32=False), t, H, a.scale)
+                if a.to_queries.bias is None and a.to_keys_values.bias is None:
+                    qkv = layers.linear(y, a.qkv_weight(), None, out_f32=False, train_w=False)     # one projection GEMM
+                    o = layers.small_attention_qkv(qkv, t, H, a.scale)
+                else:
+                    o = layers.small_attention(a.to_queries(y, out_f32=False), a.to_keys_values(y, out_f32=False), t, H, a.scale)
                 h = a.project(o, residual=hs)                 # the f32 residual adds ride in the GEMM epilogues
                 y, hs = layers.layer_norm_skip(h, lyr.norm2.weight, lyr.norm2.bias, T)
                 h = lyr.mlp(y, hs).view(n, t, d)              # fc2(relu(fc1 y)) + hs as one node (ReLU backward fused)

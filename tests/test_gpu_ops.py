@@ -335,6 +335,12 @@ def test_small_attention_fwd_bwd(n, t):
     for got, want, name in ((o, ref, "o"), (qg.grad, qr.grad, "dq"), (kvg.grad, kvr.grad, "dkv")):
         err = (got.float().cpu() - want.detach()).abs().max() / want.detach().abs().max()
         assert err < 2e-2, (name, float(err))
+    # the same kernels on ONE fused q|k|v tensor (row stride 3d): bit-identical output and gradients
+    qkv = torch.cat([q, kv], dim=1).cuda().requires_grad_(True)
+    o2 = layers.small_attention_qkv(qkv, t, H, scale)
+    o2.backward(do.cuda())
+    assert torch.equal(o2, o)
+    assert torch.equal(qkv.grad[:, :d], qg.grad) and torch.equal(qkv.grad[:, d:], kvg.grad)
 
 
 def test_fast_rcnn_inference_single_image_matches_reference():
