@@ -423,15 +423,17 @@ def sgd_clip_step(params, grads, moms, norm_ws, lr, momentum, wd, clip, first_st
 
 # ------------------------------------------------------------------------------------------------ RoIAlign
 @_timed("roi_align_forward")
-def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, dbg_grid=None, with_pooled=False):
+def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, dbg_grid=None, with_pooled=False, extra_rows=0):
     """x NHWC [N,H,W,C]; rois [K,5] f32 (batch_idx,x0,y0,x1,y1) -> [K,ph,pw,C]  (layers/roi_align.py:49-65).
-    ``with_pooled``: also returns AvgPool2d(2) of the result [K,ph/2,pw/2,C] (bit-identical to avgpool2_fwd of it)."""
+    ``with_pooled``: also returns AvgPool2d(2) of the result [K,ph/2,pw/2,C] (bit-identical to avgpool2_fwd of it).
+    ``extra_rows``: the outputs are allocated with that many more (unwritten) leading rows behind the K crops, for a caller that
+    appends maps of the same geometry without a concatenation copy."""
     require_cuda(x, rois)
     assert rois.dim() == 2 and rois.size(1) == 5 and rois.dtype == torch.float32 and rois.is_contiguous()
     N, H, W, C = x.shape
     K = rois.shape[0]
-    y = torch.empty((K, ph, pw, C), device=x.device, dtype=x.dtype)
-    yp = torch.empty((K, ph // 2, pw // 2, C), device=x.device, dtype=x.dtype) if with_pooled else None
+    y = torch.empty((K + extra_rows, ph, pw, C), device=x.device, dtype=x.dtype)
+    yp = torch.empty((K + extra_rows, ph // 2, pw // 2, C), device=x.device, dtype=x.dtype) if with_pooled else None
     check(_L().cddmsl_roi_align_forward(ptr(x), ptr(rois), ptr(y), ptr(yp), ptr(dbg_grid), N, C, H, W, K, ph, pw, spatial_scale,
                                          sampling_ratio, int(aligned), _dt(x), stream_ptr()), "cddmsl_roi_align_forward")
     return (y, yp) if with_pooled else y

@@ -372,32 +372,41 @@ def res_stage_attnpool(x, blocks, frozen, ap):
 # ------------------------------------------------------------------------------------------------
 class RoIAlignFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, rois, roi_start, out_size, scale, sampling_ratio, aligned, with_pooled=False):
-        out = hip.roi_align_forward(x, rois, out_size, out_size, scale, sampling_ratio, aligned, with_pooled=with_pooled)
+    def forward(ctx, x, rois, roi_start, out_size, scale, sampling_ratio, aligned, with_pooled=False, extra=None):
+        K, E = rois.shape[0], (0 if extra is None else extra.shape[0])
+        out = hip.roi_align_forward(x, rois, out_size, out_size, scale, sampling_ratio, aligned, with_pooled=with_pooled, extra_rows=E)
         ctx.save_for_backward(rois, roi_start)
-        ctx.meta = (tuple(x.shape), scale, sampling_ratio, aligned)
+        ctx.meta = (tuple(x.shape), scale, sampling_ratio, aligned, K)
+        y = out[0] if with_pooled else out
+        if E:                                        # maps appended behind the crops: the stage that follows runs once over both
+            y[K:].copy_(extra)
+            if with_pooled:
+                out[1][K:].copy_(hip.avgpool2_fwd(extra.contiguous()))
         if with_pooled:
             ctx.mark_non_differentiable(out[1])      # a by-product: the consumer (ResStageFn) differentiates through y alone
-            return out
         return out
 
     @staticmethod
     def backward(ctx, dy, *unused):
         rois, roi_start = ctx.saved_tensors
-        shape, scale, sr, aligned = ctx.meta
-        dx = hip.roi_align_backward(dy.contiguous(), rois, roi_start, shape, scale, sr, aligned)
-        return dx, None, None, None, None, None, None, None
+        shape, scale, sr, aligned, K = ctx.meta
+        dy = dy.contiguous()
+        dx = hip.roi_align_backward(dy[:K], rois, roi_start, shape, scale, sr, aligned)
+        dextra = dy[K:] if (dy.shape[0] > K and ctx.needs_input_grad[8]) else None
+        return dx, None, None, None, None, None, None, None, dextra
 
 
-def roi_align(x, rois, roi_start, out_size, scale, sampling_ratio, aligned=True, with_pooled=False):
+def roi_align(x, rois, roi_start, out_size, scale, sampling_ratio, aligned=True, with_pooled=False, extra=None):
     """``with_pooled`` (even out_size): the result carries its 2x2-average-pooled copy as ``y._pooled2`` -- the first block of
-    a stride-2 residual stage picks it up instead of pooling the map again (res_stage)."""
+    a stride-2 residual stage picks it up instead of pooling the map again (res_stage).  ``extra`` [E, out, out, C]: maps of
+    the crops' geometry appended behind them (rows K..K+E of the result), written into the one output buffer."""
     assert rois.dim() == 2 and rois.size(1) == 5  # layers/roi_align.py:55
+    assert extra is None or tuple(extra.shape[1:]) == (out_size, out_size, x.shape[3])
     if with_pooled and out_size % 2 == 0:
-        y, yp = RoIAlignFn.apply(x, rois, roi_start, out_size, scale, sampling_ratio, aligned, True)
+        y, yp = RoIAlignFn.apply(x, rois, roi_start, out_size, scale, sampling_ratio, aligned, True, extra)
         y._pooled2 = yp
         return y
-    return RoIAlignFn.apply(x, rois, roi_start, out_size, scale, sampling_ratio, aligned)
+    return RoIAlignFn.apply(x, rois, roi_start, out_size, scale, sampling_ratio, aligned, False, extra)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -145,8 +145,9 @@ class GeneralizedRCNN(nn.Module):
         fs, ft = gather_cat(p[:n].contiguous()), gather_cat(p[n:].contiguous())
         return layers.contrastive_loss(ft, fs), kd_loss
 
-    def _region_level_encode(self, batched_inputs):
-        """rcnn.py:422-470 up to the pooled region embeddings: (source regions, target regions), each [16 N, 1024]"""
+    def _region_level_encode(self, batched_inputs, extra_maps=None):
+        """rcnn.py:422-470 up to the pooled region embeddings: (source regions, target regions), each [16 N, 1024]; with
+        ``extra_maps`` (res4 maps of the RoI crops' geometry) a third entry: their embeddings from the same layer4 + pool pass"""
         # source and target images stacked on the batch axis: one backbone pass over 2N images, one RoI pass over
         # 2x16N regions (identical per-sample results, half the kernel launches)
         n = len(batched_inputs)
@@ -177,7 +178,7 @@ class GeneralizedRCNN(nn.Module):
                 inst = Instances(tuple(size))
                 inst.proposal_boxes = Boxes(b_)
                 props.append(inst)
-        return self.roi_heads.forward_get_features_paired(f, n, props, self.backbone.layer4, self.backbone.attnpool)
+        return self.roi_heads.forward_get_features_paired(f, n, props, self.backbone.layer4, self.backbone.attnpool, extra_maps)
 
     def forward_consistency(self, batched_inputs, clipcap_model, KD_regularization=True):
         """Both caption-consistency branches (rcnn.py:413-470) with ONE pass through the frozen mapper and ONE through the
@@ -187,12 +188,19 @@ class GeneralizedRCNN(nn.Module):
         launches over 2560-row operands disappear into the region-level ones.  Returns the three loss entries."""
         both = self.preprocess_image_train(batched_inputs)
         n = both.shape[0] // 2
-        enc_img = self._encode(self.backbone, both)                                   # [2N, 1024]
         enc_teacher = None
         if KD_regularization:
             with torch.no_grad():
                 enc_teacher = self._encode(self.offline_backbone, both[:n])
-        rs, rt = self._region_level_encode(batched_inputs)
+        # The student's layer4 + attention pool ARE the RoI head's (rcnn.py:606-612 borrows them): the 2N res4 maps of the
+        # 224x224 crops (14x14, the RoI crops' geometry) ride behind the region-level branch's RoI crops through one pass.
+        res4_img = self.backbone.forward_nhwc(both, want_res5=False)["res4"]
+        pr = self.roi_heads.pooler.output_size if hasattr(self.roi_heads, "pooler") else -1
+        if self.use_clip_c4 and tuple(res4_img.shape[1:3]) == (pr, pr):
+            rs, rt, enc_img = self._region_level_encode(batched_inputs, extra_maps=res4_img)
+        else:
+            enc_img = self.backbone.attnpool(to_nchw(self.backbone.layer4.forward_nhwc(res4_img)))
+            rs, rt = self._region_level_encode(batched_inputs)
         k = rs.shape[0]
         parts = [enc_img, rs, rt] + ([enc_teacher] if enc_teacher is not None else [])
         f = v2l(torch.cat(parts), clipcap_model)                                      # [2N + 2K (+ N), 768]

@@ -30,15 +30,17 @@ class ROIPooler(nn.Module):
         assert len(scales) == 1 and pooler_type == "ROIAlignV2"
         self.output_size, self.scale, self.sampling_ratio = output_size, scales[0], sampling_ratio
 
-    def forward_nhwc(self, feat, box_lists: List[Boxes], with_pooled=False):
-        """``with_pooled``: the crops carry their 2x2-average-pooled copy for the stride-2 stage that follows (layers.roi_align)"""
+    def forward_nhwc(self, feat, box_lists: List[Boxes], with_pooled=False, extra_maps=None):
+        """``with_pooled``: the crops carry their 2x2-average-pooled copy for the stride-2 stage that follows (layers.roi_align);
+        ``extra_maps``: maps of the crops' geometry appended behind them"""
         dev = feat.device
         counts = [len(b) for b in box_lists]
         # convert_boxes_to_pooler_format poolers.py:68-95: rois grouped by image, (batch_idx, x0, y0, x1, y1)
         bidx = to_device_async(torch.repeat_interleave(torch.arange(len(counts), dtype=torch.float32), torch.tensor(counts)), dev)
         rois = torch.cat([bidx[:, None], torch.cat([b.tensor.float() for b in box_lists])], dim=1).contiguous()
         start = to_device_async(torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32), dev)
-        return layers.roi_align(feat, rois, start, self.output_size, self.scale, self.sampling_ratio, True, with_pooled=with_pooled)
+        return layers.roi_align(feat, rois, start, self.output_size, self.scale, self.sampling_ratio, True, with_pooled=with_pooled,
+                                extra=extra_maps)
 
     def forward(self, x, box_lists):
         return to_nchw(self.forward_nhwc(to_nhwc(x[0]), box_lists))
@@ -298,13 +300,15 @@ class CLIPRes5ROIHeads(nn.Module):
         self.storage["roi_head/num_bg_samples"] = sum(nbg) / max(len(nbg), 1)
         return out
 
-    def _pooled_embeddings(self, feat_nhwc, boxes, res5, attnpool):
+    def _pooled_embeddings(self, feat_nhwc, boxes, res5, attnpool, extra_maps=None):
         """RoIAlign -> layer4 -> attention pool (clip_roi_heads.py:160-165); with the package's own modules the last two run
-        as one composition (the stage's ReLU backward rides in the pool's backward)"""
+        as one composition (the stage's ReLU backward rides in the pool's backward).  ``extra_maps`` [E, 14, 14, C]: res4 maps
+        that go through the same layer4 + attention pool (the image-level consistency branch's 224x224 crops, rcnn.py:255-262):
+        they ride behind the RoI crops, the result has their embeddings in rows K.."""
         from .backbone import AttentionPool2d, ResStage
         fused = isinstance(res5, ResStage) and isinstance(attnpool, AttentionPool2d)
         # (CLIP's layer4 is stride 2 with an AvgPool2d on the downsample path: RoIAlign hands it the pooled crops as well)
-        x = self.pooler.forward_nhwc(feat_nhwc, boxes, with_pooled=fused and res5[0].stride > 1)
+        x = self.pooler.forward_nhwc(feat_nhwc, boxes, with_pooled=fused and res5[0].stride > 1, extra_maps=extra_maps)
         if fused:
             return res5.forward_nhwc(x, then_attnpool=attnpool)
         return attnpool(to_nchw(res5.forward_nhwc(x)))
@@ -317,12 +321,15 @@ class CLIPRes5ROIHeads(nn.Module):
         return (self._pooled_embeddings(to_nhwc(features_src[self.in_features[0]]), boxes, res5, attnpool),
                 self._pooled_embeddings(to_nhwc(features_trgt[self.in_features[0]]), boxes, res5, attnpool))
 
-    def forward_get_features_paired(self, feat_cat_nhwc, num_images, proposals, res5, attnpool):
+    def forward_get_features_paired(self, feat_cat_nhwc, num_images, proposals, res5, attnpool, extra_maps=None):
         """Same result as ``forward_get_features`` when source and target maps are stacked along the batch axis
-        (images [0,B) = source, [B,2B) = target): ONE RoIAlign / layer4 / attention-pool pass over 2K regions."""
+        (images [0,B) = source, [B,2B) = target): ONE RoIAlign / layer4 / attention-pool pass over 2K regions.
+        With ``extra_maps`` a third result: their embeddings (``_pooled_embeddings``)."""
         boxes = [p.proposal_boxes for p in proposals]
-        att = self._pooled_embeddings(feat_cat_nhwc, boxes + boxes, res5, attnpool)
-        k = att.shape[0] // 2
+        att = self._pooled_embeddings(feat_cat_nhwc, boxes + boxes, res5, attnpool, extra_maps)
+        k = sum(len(b) for b in boxes)
+        if extra_maps is not None:
+            return att[:k], att[k:2 * k], att[2 * k:]
         return att[:k], att[k:]
 
     def forward(self, images, features, proposals, targets=None, res5=None, attnpool=None):
