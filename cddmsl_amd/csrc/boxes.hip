@@ -119,11 +119,13 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* mask
   }
   if (t == 0) { s_cnt = 0; s_km = 0; }
   int cnt = 0;                                    // (kept so far; wave 0's copy is the authoritative one)
+  unsigned long long dnext = (wv == 0 && lane < n) ? m[(long)lane * nw] : 0ull;
   for (int c = 0; c < nw; ++c) {
     __syncthreads();                              // rem[c] is final: every earlier chunk has been applied
     if (wv == 0) {
       const int i = c * 64 + lane;
-      const unsigned long long d = i < n ? m[(long)i * nw + c] : 0ull;
+      const unsigned long long d = dnext;         // this chunk's diagonal word, requested one chunk ago (it depends on no decision)
+      dnext = (c + 1 < nw && i + 64 < n) ? m[(long)(i + 64) * nw + c + 1] : 0ull;
       const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
       unsigned long long cur = rem[c], km = 0;
       const int cnt0 = cnt;
@@ -137,15 +139,31 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* mask
       if (lane == 0) { s_km = km; s_cnt = cnt; }
     }
     __syncthreads();
-    const unsigned long long km = s_km;
+    const unsigned long long kmv = s_km;
     if (s_cnt >= max_keep) break;
+    // the kept rows of this chunk, OR-ed into the words behind it: the row list is block-uniform (scalar registers), and the
+    // rows are requested sixteen at a time -- one memory round trip per sixteen kept rows instead of one per row (a repeated
+    // row pads the last group: OR is idempotent)
+    unsigned long long km = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kmv >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kmv);
     if (km) {
       for (int ww = c + 1 + t; ww < nw; ww += 256) {
         unsigned long long acc = rem[ww], bits = km;
+        const unsigned long long* col = m + (long)c * 64 * nw + ww;
         while (bits) {
-          const int b = __builtin_ctzll(bits);
+          int b[16];
+          b[0] = __builtin_ctzll(bits);
           bits &= bits - 1;
-          acc |= m[(long)(c * 64 + b) * nw + ww];
+#pragma unroll
+          for (int u = 1; u < 16; ++u) {
+            b[u] = bits ? __builtin_ctzll(bits) : b[0];
+            bits &= bits - 1;                     // (0 & anything stays 0)
+          }
+          unsigned long long r[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) r[u] = col[(long)b[u] * nw];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc |= r[u];
         }
         rem[ww] = acc;
       }
