@@ -142,7 +142,16 @@ class ConvFn(torch.autograd.Function):
             assert stride == 1, "input gradient of a strided conv is not on the hot path"
             _, wd = ctx.pw.get(T, need_dgrad=True)
             KH = _ohwi(w).shape[1]
-            dx = hip.conv_fwd(dy, wd, stride=1, pad=KH - 1 - pad)
+            Kd, rows = dy.shape[-1], dy.numel() // dy.shape[-1]
+            if KH == 1 and _ohwi(w).shape[2] == 1 and pad == 0 and rows <= 1024 and Kd >= 8192 and Kd % (16 * 64) == 0:
+                # few rows, very long reduction (the mapper's 1024 -> 40*768 linear: 544 x 1024 outputs over K = 30720 would be
+                # 12 tiles on 256 CUs): 16 reduction slices as one batched launch, f32 partial sums added afterwards
+                S, N = 16, x.shape[-1]
+                part = torch.empty(S, rows, N, device=dy.device, dtype=torch.float32)
+                hip.gemm_nt_batched(dy, wd, part, rows, N, Kd // S, Kd, Kd, N, S, Kd // S, Kd // S, rows * N)
+                dx = part.sum(0).to(T).view(x.shape)
+            else:
+                dx = hip.conv_fwd(dy, wd, stride=1, pad=KH - 1 - pad)
         # y = conv + residual (no ReLU with a residual): the residual's gradient is the incoming one, as it came
         return dx, None, None, None, None, None, None, None, None, (dy_in if ctx.needs_input_grad[9] else None)
 
