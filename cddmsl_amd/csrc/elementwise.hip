@@ -243,23 +243,44 @@ __global__ void k_attn_tokens_fwd(const char* x, const float* pos, char* tok, in
   }
 }
 // dx[k][p] = dtok[k][p+1] + dtok[k][0]/P, zeroed where relu_mask[k][p] <= 0 (relu_mask = the pooled map itself when it is the
-// output of a ReLU: the ReLU backward of the residual stage in front of the pool rides in this pass)
+// output of a ReLU: the ReLU backward of the residual stage in front of the pool rides in this pass), and -- gpos given --
+// gpos[t][:] += sum_k dtok[k][t][:] for t <= P (the positional embedding's gradient: dtok is read once for both).
+// grid: x = 256-chunk column blocks, y = token row t, z = slab of regions; a thread owns one 16-byte column chunk of one
+// token row, walks its slab's regions and ends with one atomic per column.
 template <typename T>
-__global__ void k_attn_tokens_bwd(const char* dtok, const char* relu_mask, char* dx, int K, int P, int TP, int cch) {
-  long total = (long)K * P * cch;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    int c = i % cch; long q = i / cch;
-    int p = q % P; long k = q / P;
-    float a[8], b[8], m[8], o[8];
-    Elt<T>::unpack(((const u32x4*)dtok)[(k * TP + p + 1) * cch + c], a);
-    Elt<T>::unpack(((const u32x4*)dtok)[(k * TP) * cch + c], b);
-    if (relu_mask) Elt<T>::unpack(((const u32x4*)relu_mask)[i], m);
+__global__ __launch_bounds__(256) void k_attn_tokens_bwd(const char* __restrict__ dtok, const char* __restrict__ relu_mask, char* __restrict__ dx, float* __restrict__ gpos, int K,
+                                                         int P, int TP, int cch, int slab) {
+  constexpr int V = Elt<T>::VEC;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (c >= cch || (t == 0 && !gpos)) return;
+  const int k0 = blockIdx.z * slab, k1 = min(K, k0 + slab);
+  float acc[V];
 #pragma unroll
-    for (int j = 0; j < Elt<T>::VEC; ++j) {
-      o[j] = a[j] + b[j] / (float)P;
-      if (relu_mask && !(m[j] > 0.f)) o[j] = 0.f;
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  const u32x4* src = (const u32x4*)dtok;
+#pragma unroll 4
+  for (int k = k0; k < k1; ++k) {
+    float a[8];
+    Elt<T>::unpack(src[((long)k * TP + t) * cch + c], a);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] += a[j];
+    if (t > 0 && dx) {
+      float b[8], m[8], o[8];
+      const long oi = ((long)k * P + t - 1) * cch + c;
+      Elt<T>::unpack(src[(long)k * TP * cch + c], b);
+      if (relu_mask) Elt<T>::unpack(((const u32x4*)relu_mask)[oi], m);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        o[j] = a[j] + b[j] / (float)P;
+        if (relu_mask && !(m[j] > 0.f)) o[j] = 0.f;
+      }
+      ((u32x4*)dx)[oi] = Elt<T>::pack(o);
     }
-    ((u32x4*)dx)[i] = Elt<T>::pack(o);
+  }
+  if (gpos) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) atomicAdd(gpos + (long)t * cch * V + (long)c * V + j, acc[j]);
   }
 }
 
@@ -461,14 +482,16 @@ extern "C" int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok
   return launch_status();
 }
 
-extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, const void* relu_mask, void* dx, int K, int P, int TP, int C, int dtype,
-                                      void* stream) {
+extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, const void* relu_mask, void* dx, float* gpos, int K, int P, int TP, int C,
+                                      int dtype, void* stream) {
   int es = dtype == 0 ? 2 : 4;
-  if ((C * es) % 16 || P <= 0 || TP < P + 1) return CDDMSL_ERR_ARG;
+  if ((C * es) % 16 || P <= 0 || TP < P + 1 || K < 0 || (!dx && !gpos)) return CDDMSL_ERR_ARG;
   int cch = C * es / 16;
-  long total = (long)K * P * cch;
-  if (total == 0) return CDDMSL_OK;
-  DISPATCH(dtype, k_attn_tokens_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (const char*)relu_mask, (char*)dx, K, P, TP, cch));
+  if (K == 0) return CDDMSL_OK;
+  int slab = 128;                                          // (64-128 regions per block measured best: 16 -> +0.6 ms, 512 -> +0.5 ms)
+  while ((K + slab - 1) / slab > 65535) slab *= 2;
+  dim3 grid((unsigned)((cch + 255) / 256), (unsigned)(P + 1), (unsigned)((K + slab - 1) / slab));
+  DISPATCH(dtype, k_attn_tokens_bwd, <<<grid, dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (const char*)relu_mask, (char*)dx, gpos, K, P, TP, cch, slab));
   return launch_status();
 }
 

@@ -35,7 +35,7 @@ def _L():
         L.cddmsl_avgpool2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
         L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_attn_tokens_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
-        L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
+        L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_gemm_nt_batched.argtypes = [vp] * 4 + [ci] * 7 + [c_long] * 3 + [ci, ci, vp]
         L.cddmsl_gemm_tn_batched.argtypes = [vp] * 3 + [ci] * 7 + [c_long] * 3 + [ci, ci, vp]
         L.cddmsl_relu_bwd.argtypes = [vp, vp, vp, c_long, ci, ci, vp]
@@ -332,14 +332,17 @@ def attn_tokens_fwd(x, pos, tp=None):
 
 
 @_timed("attn_tokens_bwd")
-def attn_tokens_bwd(dtok, P, relu_mask=None):
-    """dtok [K,TP,C] -> dx [K,P,C], zeroed where relu_mask [K,P,C] <= 0"""
-    require_cuda(dtok, relu_mask)
+def attn_tokens_bwd(dtok, P, relu_mask=None, gpos=None, want_dx=True):
+    """dtok [K,TP,C] -> dx [K,P,C], zeroed where relu_mask [K,P,C] <= 0; gpos (f32 [P+1,C], accumulated into) += the
+    per-token column sums of dtok (the positional embedding's gradient) in the same pass"""
+    require_cuda(dtok, relu_mask, gpos)
     K, TP, C = dtok.shape
     assert dtok.is_contiguous()
     assert relu_mask is None or (relu_mask.is_contiguous() and relu_mask.dtype == dtok.dtype and relu_mask.numel() == K * P * C)
-    dx = torch.empty((K, P, C), device=dtok.device, dtype=dtok.dtype)
-    check(_L().cddmsl_attn_tokens_bwd(ptr(dtok), ptr(relu_mask), ptr(dx), K, P, TP, C, _dt(dtok), stream_ptr()), "cddmsl_attn_tokens_bwd")
+    assert gpos is None or (gpos.is_contiguous() and gpos.dtype == torch.float32 and tuple(gpos.shape) == (P + 1, C))
+    assert want_dx or gpos is not None
+    dx = torch.empty((K, P, C), device=dtok.device, dtype=dtok.dtype) if want_dx else None
+    check(_L().cddmsl_attn_tokens_bwd(ptr(dtok), ptr(relu_mask), ptr(dx), ptr(gpos), K, P, TP, C, _dt(dtok), stream_ptr()), "cddmsl_attn_tokens_bwd")
     return dx
 
 

@@ -536,11 +536,13 @@ class AttnPoolFn(torch.autograd.Function):
             hip.colsum(dq0, out=_grad_buf(ap.q_b))
         _, wqd = ap.pq.get(T, True)
         dtok[:, 0, :] += hip.conv_fwd(dq0.view(1, 1, K, C), wqd).view(K, C)
-        if train:
-            gpos = hip.colsum(dtok.view(-1, C), period=TP)
-            _grad_buf(ap.pos).add_(gpos[:P + 1])
-        dx = hip.attn_tokens_bwd(dtok, P, ctx.relu_src).view(K, h, w, C) if ctx.needs_input_grad[0] else None
-        return dx, None, None, None
+        # one pass over dtok: the positional embedding's gradient (column sums per token row) and the map's gradient
+        gpos = _grad_buf(ap.pos) if train else None
+        want_dx = ctx.needs_input_grad[0]
+        dx = None
+        if want_dx or train:
+            dx = hip.attn_tokens_bwd(dtok, P, ctx.relu_src if want_dx else None, gpos, want_dx)
+        return (dx.view(K, h, w, C) if want_dx else None), None, None, None
 
 
 def attnpool(x, ap):

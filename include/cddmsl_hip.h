@@ -104,8 +104,10 @@ int cddmsl_iou_match_batched(const float* gt, const int* gt_off, const float* pr
  * reassociated into the batched GEMMs above (cddmsl_amd/layers.py::AttnPoolFn) ------------------------------------- */
 int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int TP, int C, int dtype, void* stream);
 /* relu_mask (nullable, [K][P][C]): dx is zeroed where it is <= 0 -- the pooled map when it is a ReLU output (layer4 -> attnpool,
- * clip_roi_heads.py:160-165), so the stage's ReLU backward needs no pass of its own */
-int cddmsl_attn_tokens_bwd(const void* dtok, const void* relu_mask, void* dx, int K, int P, int TP, int C, int dtype, void* stream);
+ * clip_roi_heads.py:160-165), so the stage's ReLU backward needs no pass of its own.  gpos (nullable, f32 [P+1][C]) accumulates
+ * (atomics) the positional embedding's gradient sum_k dtok[k][t][:] in the same pass; dx may be NULL when only gpos is wanted */
+int cddmsl_attn_tokens_bwd(const void* dtok, const void* relu_mask, void* dx, float* gpos, int K, int P, int TP, int C, int dtype,
+                           void* stream);
 
 /* ---- fused multi-head attention for short sequences: the ClipCap mapper's softmax(QK^T * scale) V (no mask), 80 tokens x 8
  * heads of 96 (modeling/backbone/clipcap/clipcap.py:59-83).  bf16 only (dtype 0), dh == 96, t <= 96; element (s, i, h, c) of

@@ -443,3 +443,28 @@ def test_iou_match_batched_equals_per_image():
         m1, l1 = hip.iou_match(gt.contiguous(), pr.contiguous(), [0.5], [0, 1], False)
         assert torch.equal(m[off:off + counts[n]], m1) and torch.equal(l[off:off + counts[n]], l1), n
         off += counts[n]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_tokens_bwd_with_positional_gradient(dtype):
+    """dx[k][p] = dtok[k][p+1] + dtok[k][0] / P (masked where the pooled map is <= 0) and, in the same pass, the positional
+    embedding's gradient sum_k dtok[k][t] accumulated into an f32 buffer (clip_backbone.py:86-88 backward) -- vs torch."""
+    from cddmsl_amd import hip
+    K, P, TP, C = 300, 49, 56, 64
+    g = torch.Generator().manual_seed(3)
+    dtok = torch.randn(K, TP, C, generator=g).to(dtype).cuda()
+    mask = torch.randn(K, P, C, generator=g).to(dtype).cuda()
+    gpos = torch.full((P + 1, C), 0.5, device="cuda")
+    dx = hip.attn_tokens_bwd(dtok, P, mask, gpos)
+    d = dtok.float()
+    Pt = torch.full((1, 1, 1), float(P), device="cuda")        # a tensor divisor: true division (a Python scalar becomes * (1/P))
+    want = (d[:, 1:P + 1] + d[:, :1] / Pt) * (mask.float() > 0)
+    assert torch.equal(dx, want.to(dtype))
+    wpos = 0.5 + d[:, :P + 1].double().sum(0)
+    assert float((gpos.double() - wpos).abs().max()) < 1e-3
+    # gradient-only and map-only forms
+    gpos2 = torch.zeros(P + 1, C, device="cuda")
+    assert hip.attn_tokens_bwd(dtok, P, None, gpos2, want_dx=False) is None
+    assert float((gpos2.double() - (wpos - 0.5)).abs().max()) < 1e-3
+    dx2 = hip.attn_tokens_bwd(dtok, P)
+    assert torch.equal(dx2, (d[:, 1:P + 1] + d[:, :1] / Pt).to(dtype))
