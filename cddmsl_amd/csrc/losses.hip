@@ -183,6 +183,110 @@ template <> struct OutT<__bf16> { __device__ static __forceinline__ void st(void
                                   __device__ static __forceinline__ float ld(const void* p, long i) { return bf2f(((const unsigned short*)p)[i]); } };
 template <> struct OutT<float> { __device__ static __forceinline__ void st(void* p, long i, float v) { ((float*)p)[i] = v; }
                                  __device__ static __forceinline__ float ld(const void* p, long i) { return ((const float*)p)[i]; } };
+// four consecutive elements (index in units of 4 elements)
+__device__ __forceinline__ void st4(__bf16*, void* p, long i4, float4 v) { ((uint2*)p)[i4] = make_uint2(pack2bf(v.x, v.y), pack2bf(v.z, v.w)); }
+__device__ __forceinline__ void st4(float*, void* p, long i4, float4 v) { ((float4*)p)[i4] = v; }
+__device__ __forceinline__ float4 ld4(__bf16*, const void* p, long i4) {
+  const uint2 u = ((const uint2*)p)[i4];
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 ld4(float*, const void* p, long i4) { return ((const float4*)p)[i4]; }
+
+// Rows of NSEG x 256 columns (the mapper's 768): one wave per row, the row held in registers -- every operand is read once, in
+// 16-byte (f32) / 8-byte (bf16) pieces.  Same expressions as the generic kernels below; only the order of the row sums differs.
+template <typename T, int NSEG>
+__global__ __launch_bounds__(256) void k_layernorm_fwd_v(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, void* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, long R, float eps) {
+  constexpr int D = NSEG * 256;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float4* xr = (const float4*)(x + r * D);
+  float4 v[NSEG];
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) v[s] = xr[s * 64 + lane];
+  float sum = 0.f;
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) sum += (v[s].x + v[s].y) + (v[s].z + v[s].w);
+  const float mu = wave_sum(sum) / (float)D;
+  float var = 0.f;
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    const float a = v[s].x - mu, b = v[s].y - mu, c = v[s].z - mu, d = v[s].w - mu;
+    var += (a * a + b * b) + (c * c + d * d);
+  }
+  const float rs = rsqrtf(wave_sum(var) / (float)D + eps);
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    const float4 g = ((const float4*)gamma)[s * 64 + lane], b = ((const float4*)beta)[s * 64 + lane];
+    float4 o;
+    o.x = (v[s].x - mu) * rs * g.x + b.x; o.y = (v[s].y - mu) * rs * g.y + b.y;
+    o.z = (v[s].z - mu) * rs * g.z + b.z; o.w = (v[s].w - mu) * rs * g.w + b.w;
+    st4((T*)nullptr, y, r * (D / 4) + s * 64 + lane, o);
+  }
+  if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+}
+template <typename T, int NSEG>
+__global__ __launch_bounds__(256) void k_layernorm_bwd_v(const void* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* dx, long R, int accumulate) {
+  constexpr int D = NSEG * 256;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float4* xr = (const float4*)(x + r * D);
+  float4* dxr = (float4*)(dx + r * D);
+  const float mu = mean[r], rs = rstd[r];
+  float4 g[NSEG], xh[NSEG], o[NSEG];
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    const float4 d4 = ld4((T*)nullptr, dy, r * (D / 4) + s * 64 + lane), ga = ((const float4*)gamma)[s * 64 + lane], xv = xr[s * 64 + lane];
+    if (accumulate) o[s] = dxr[s * 64 + lane];
+    g[s] = make_float4(d4.x * ga.x, d4.y * ga.y, d4.z * ga.z, d4.w * ga.w);
+    xh[s] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+  }
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    sg += (g[s].x + g[s].y) + (g[s].z + g[s].w);
+    sgx += (g[s].x * xh[s].x + g[s].y * xh[s].y) + (g[s].z * xh[s].z + g[s].w * xh[s].w);
+  }
+  sg = wave_sum(sg) / (float)D; sgx = wave_sum(sgx) / (float)D;
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) {
+    float4 v;
+    v.x = rs * (g[s].x - sg - xh[s].x * sgx); v.y = rs * (g[s].y - sg - xh[s].y * sgx);
+    v.z = rs * (g[s].z - sg - xh[s].z * sgx); v.w = rs * (g[s].w - sg - xh[s].w * sgx);
+    if (accumulate) { v.x = o[s].x + v.x; v.y = o[s].y + v.y; v.z = o[s].z + v.z; v.w = o[s].w + v.w; }
+    dxr[s * 64 + lane] = v;
+  }
+}
+template <typename T> bool layernorm_fwd_v(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                           long R, int D, float eps, hipStream_t st) {
+  const dim3 grid((unsigned)((R + 3) / 4)), blk(256);
+  switch (D) {
+    case 256: k_layernorm_fwd_v<T, 1><<<grid, blk, 0, st>>>(x, gamma, beta, y, mean, rstd, R, eps); return true;
+    case 512: k_layernorm_fwd_v<T, 2><<<grid, blk, 0, st>>>(x, gamma, beta, y, mean, rstd, R, eps); return true;
+    case 768: k_layernorm_fwd_v<T, 3><<<grid, blk, 0, st>>>(x, gamma, beta, y, mean, rstd, R, eps); return true;
+    case 1024: k_layernorm_fwd_v<T, 4><<<grid, blk, 0, st>>>(x, gamma, beta, y, mean, rstd, R, eps); return true;
+  }
+  return false;
+}
+template <typename T> bool layernorm_bwd_v(const void* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                           float* dx, long R, int D, int accumulate, hipStream_t st) {
+  const dim3 grid((unsigned)((R + 3) / 4)), blk(256);
+  switch (D) {
+    case 256: k_layernorm_bwd_v<T, 1><<<grid, blk, 0, st>>>(dy, x, gamma, mean, rstd, dx, R, accumulate); return true;
+    case 512: k_layernorm_bwd_v<T, 2><<<grid, blk, 0, st>>>(dy, x, gamma, mean, rstd, dx, R, accumulate); return true;
+    case 768: k_layernorm_bwd_v<T, 3><<<grid, blk, 0, st>>>(dy, x, gamma, mean, rstd, dx, R, accumulate); return true;
+    case 1024: k_layernorm_bwd_v<T, 4><<<grid, blk, 0, st>>>(dy, x, gamma, mean, rstd, dx, R, accumulate); return true;
+  }
+  return false;
+}
+__host__ inline bool aligned16(const void* a, const void* b, const void* c, const void* d, const void* e = nullptr) {
+  return ((((size_t)a) | ((size_t)b) | ((size_t)c) | ((size_t)d) | ((size_t)e)) & 15) == 0;
+}
 
 // one wave per row
 template <typename T>
@@ -273,6 +377,10 @@ extern "C" int cddmsl_layernorm_fwd(const float* x, const float* gamma, const fl
   if (R < 0 || D <= 0 || (dtype != 0 && dtype != 1)) return CDDMSL_ERR_ARG;
   if (R == 0) return CDDMSL_OK;
   dim3 grid((unsigned)((R + 3) / 4));
+  if (aligned16(x, gamma, beta, y) &&
+      (dtype == 0 ? layernorm_fwd_v<__bf16>(x, gamma, beta, y, mean, rstd, R, D, eps, (hipStream_t)stream)
+                  : layernorm_fwd_v<float>(x, gamma, beta, y, mean, rstd, R, D, eps, (hipStream_t)stream)))
+    return launch_status();
   if (dtype == 0) k_layernorm_fwd<__bf16><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, gamma, beta, y, mean, rstd, R, D, eps);
   else k_layernorm_fwd<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>(x, gamma, beta, y, mean, rstd, R, D, eps);
   return launch_status();
@@ -282,6 +390,10 @@ extern "C" int cddmsl_layernorm_bwd(const void* dy, const float* x, const float*
   if (R < 0 || D <= 0 || (dtype != 0 && dtype != 1)) return CDDMSL_ERR_ARG;
   if (R == 0) return CDDMSL_OK;
   dim3 grid((unsigned)((R + 3) / 4));
+  if (aligned16(dy, x, gamma, dx) &&
+      (dtype == 0 ? layernorm_bwd_v<__bf16>(dy, x, gamma, mean, rstd, dx, R, D, accumulate, (hipStream_t)stream)
+                  : layernorm_bwd_v<float>(dy, x, gamma, mean, rstd, dx, R, D, accumulate, (hipStream_t)stream)))
+    return launch_status();
   if (dtype == 0) k_layernorm_bwd<__bf16><<<grid, dim3(256), 0, (hipStream_t)stream>>>(dy, x, gamma, mean, rstd, dx, R, D, accumulate);
   else k_layernorm_bwd<float><<<grid, dim3(256), 0, (hipStream_t)stream>>>(dy, x, gamma, mean, rstd, dx, R, D, accumulate);
   return launch_status();

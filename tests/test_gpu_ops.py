@@ -468,3 +468,29 @@ def test_attn_tokens_bwd_with_positional_gradient(dtype):
     assert float((gpos2.double() - (wpos - 0.5)).abs().max()) < 1e-3
     dx2 = hip.attn_tokens_bwd(dtok, P)
     assert torch.equal(dx2, (d[:, 1:P + 1] + d[:, :1] / Pt).to(dtype))
+
+
+@pytest.mark.parametrize("D", [200, 512, 768, 1024])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_kernels_all_widths(D, dtype):
+    """Generic kernel (any width) and the register-resident one (whole 256-column segments): forward, backward and the
+    accumulating backward vs torch, with the operand dtype of the mapper's bf16 path and of the f32 parity path."""
+    from cddmsl_amd import hip
+    g = torch.Generator().manual_seed(D)
+    R = 131
+    x = torch.randn(R, D, generator=g).cuda()
+    gam, bet = (torch.rand(D, generator=g) + 0.5).cuda(), (torch.randn(D, generator=g) * 0.1).cuda()
+    dy = torch.randn(R, D, generator=g).to(dtype).cuda()
+    skip = torch.randn(R, D, generator=g).cuda()
+    y, mean, rstd = hip.layernorm_fwd(x, gam, bet, dtype)
+    xr = x.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (D,), gam, bet)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((y.float() - ref.detach()).abs().max()) < tol
+    (ref * dy.float()).sum().backward()
+    dx = hip.layernorm_bwd(dy, x, gam, mean, rstd)
+    assert float((dx - xr.grad).abs().max()) < 2e-5 * max(1.0, float(xr.grad.abs().max()))
+    acc = skip.clone()
+    out = hip.layernorm_bwd(dy, x, gam, mean, rstd, accumulate_into=acc)
+    assert out.data_ptr() == acc.data_ptr()
+    assert float((acc - (skip + xr.grad)).abs().max()) < 2e-5 * max(1.0, float(xr.grad.abs().max()))
