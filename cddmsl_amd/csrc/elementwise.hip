@@ -354,10 +354,21 @@ constexpr int SGD_MAX = 96;
 struct SgdBatch { SgdItem it[SGD_MAX]; int count; };
 
 __global__ void k_sqnorm(SgdBatch b, float* norms) {
-  // grid.y = tensor, grid.x = slab
+  // grid.y = tensor, grid.x = slab; 16-byte accesses when the gradient view is 16-byte aligned (views into the flat gradient
+  // buffer start wherever the tensors before them end), scalar otherwise and for the last n % 4 elements
   const SgdItem& t = b.it[blockIdx.y];
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
   float s = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += (long)gridDim.x * blockDim.x) {
+  long done = 0;
+  if ((((size_t)t.g) & 15) == 0) {
+    const long n4 = t.n >> 2;
+    for (long i = tid; i < n4; i += nth) {
+      const float4 g = ((const float4*)t.g)[i];
+      s += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
+    }
+    done = n4 << 2;
+  }
+  for (long i = done + tid; i < t.n; i += nth) {
     float g = t.g[i];
     s += g * g;
   }
@@ -367,16 +378,36 @@ __global__ void k_sqnorm(SgdBatch b, float* norms) {
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(norms + blockIdx.y, red[0] + red[1] + red[2] + red[3]);
 }
+__device__ __forceinline__ void sgd_one(float& p, float g, float& m, float coef, float lr, float momentum, float wd, int first_step) {
+  g = g * coef + wd * p;
+  m = first_step ? g : momentum * m + g;
+  p = p - lr * m;
+}
 __global__ void k_sgd(SgdBatch b, const float* norms, float lr, float momentum, float wd, float clip, int first_step) {
   const SgdItem& t = b.it[blockIdx.y];
   float nrm = sqrtf(norms[blockIdx.y]);
   float coef = fminf(clip / (nrm + 1e-6f), 1.0f);   // torch.nn.utils.clip_grad_norm_
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += (long)gridDim.x * blockDim.x) {
-    float p = t.p[i];
-    float g = t.g[i] * coef + wd * p;
-    float m = first_step ? g : momentum * t.m[i] + g;
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+  long done = 0;
+  if (((((size_t)t.g) | ((size_t)t.p) | ((size_t)t.m)) & 15) == 0) {
+    const long n4 = t.n >> 2;
+    for (long i = tid; i < n4; i += nth) {
+      float4 p = ((float4*)t.p)[i], m = first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : ((float4*)t.m)[i];
+      const float4 g = ((const float4*)t.g)[i];
+      sgd_one(p.x, g.x, m.x, coef, lr, momentum, wd, first_step);
+      sgd_one(p.y, g.y, m.y, coef, lr, momentum, wd, first_step);
+      sgd_one(p.z, g.z, m.z, coef, lr, momentum, wd, first_step);
+      sgd_one(p.w, g.w, m.w, coef, lr, momentum, wd, first_step);
+      ((float4*)t.m)[i] = m;
+      ((float4*)t.p)[i] = p;
+    }
+    done = n4 << 2;
+  }
+  for (long i = done + tid; i < t.n; i += nth) {
+    float p = t.p[i], m = first_step ? 0.f : t.m[i];
+    sgd_one(p, t.g[i], m, coef, lr, momentum, wd, first_step);
     t.m[i] = m;
-    t.p[i] = p - lr * m;
+    t.p[i] = p;
   }
 }
 
