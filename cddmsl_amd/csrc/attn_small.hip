@@ -195,7 +195,7 @@ __global__ __launch_bounds__(192) void k_attn_small_fwd(AttnArgs p) {
   rows_out(Pi, op, p.ldo, p.t, i0, lane);
 }
 
-__global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
+__global__ __launch_bounds__(192, 2) void k_attn_small_bwd(AttnArgs p) {
   // Images: Q, K, dO (each also contracted along its rows) and ONE image that holds P for dV and then dS for dQ / dK; V is
   // only ever contracted along its columns (dP = dO V^T) and stays in registers.  78 KiB -> 2 workgroups per CU.
   __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
   char* dqp = p.dq + (row0 * p.ldq + h * AT) * 2;
   char* dkp = p.dk + (row0 * p.ldk + h * AT) * 2;
   char* dvp = p.dv + (row0 * p.ldv + h * AT) * 2;
-  f32x16 av[3], aq[3], ak[3];
+  f32x16 av[3];
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
 #pragma unroll
@@ -246,10 +246,16 @@ __global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) mma(av[ct], frag_rows(Xi, i0, kk, lane), frag_rows(Di, ct * 32, kk, lane));   // dV[j] = sum_i P[i][j] dO[i]   (j0 = i0)
   }
-  __syncthreads();                                  // every wave is done reading P: the image now takes dS
+  __syncthreads();                                  // every wave is done reading P (the image now takes dS) and dO
+  // dV leaves right away through the dO image (dead from here on; own rows): its 48 accumulators are free before dQ / dK
+  // need theirs -- 96 instead of 144 accumulation registers, which is what lets two workgroups share a CU
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) put_tile(Di, i0, ct * 32, av[ct], lane);
+  rows_out(Di, dvp, p.ldv, p.t, i0, lane);
 #pragma unroll
   for (int jt = 0; jt < 3; ++jt) put_tile(Xi, i0, jt * 32, dP[jt], lane);
   __syncthreads();
+  f32x16 aq[3], ak[3];
 #pragma unroll
   for (int ct = 0; ct < 3; ++ct) {
 #pragma unroll
@@ -265,11 +271,9 @@ __global__ __launch_bounds__(192) void k_attn_small_bwd(AttnArgs p) {
   for (int ct = 0; ct < 3; ++ct) {
     put_tile(Qi, i0, ct * 32, aq[ct], lane);
     put_tile(Ki, i0, ct * 32, ak[ct], lane);
-    put_tile(Di, i0, ct * 32, av[ct], lane);
   }
   rows_out(Qi, dqp, p.ldq, p.t, i0, lane);
   rows_out(Ki, dkp, p.ldk, p.t, i0, lane);
-  rows_out(Di, dvp, p.ldv, p.t, i0, lane);
 }
 
 int check(const AttnArgs& a, int dh, int dtype) {
