@@ -50,7 +50,8 @@ __global__ void k_preprocess(const unsigned char* img, char* out, int n, int h, 
   // one thread per padded output pixel of image n; out[n][y][x][0..Cp)
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)Hp * Wp) return;
-  int x = i % Wp, y = i / Wp;
+  const unsigned ii = (unsigned)i;                 // (Hp * Wp < 2^31: a 32-bit division)
+  int x = ii % (unsigned)Wp, y = ii / (unsigned)Wp;
   float v[3] = {0.f, 0.f, 0.f};
   if (y < h && x < w) {
     long o = (long)y * w + x, pl = (long)h * w;
@@ -59,6 +60,11 @@ __global__ void k_preprocess(const unsigned char* img, char* out, int n, int h, 
     v[2] = ((float)img[2 * pl + o] / div - m2) / s2;
   }
   char* dst = out + (((long)n * Hp + y) * Wp + x) * Cp * Elt<T>::ES;
+  if (Cp == Elt<T>::VEC) {                         // a pixel is one 16-byte chunk (the layout the stem conv reads): one store
+    float o[8] = {v[0], v[1], v[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+    *(u32x4*)dst = Elt<T>::pack(o);
+    return;
+  }
   for (int c = 0; c < Cp; ++c) Elt<T>::st(dst + c * Elt<T>::ES, c < 3 ? v[c] : 0.f);
 }
 
@@ -101,6 +107,11 @@ __global__ void k_preprocess224(const unsigned char* img, char* out, int n, int 
   }
   float v[3] = {(acc[0] - m0) / s0, (acc[1] - m1) / s1, (acc[2] - m2) / s2};
   char* dst = out + (((long)n * S + oy) * S + ox) * Cp * Elt<T>::ES;
+  if (Cp == Elt<T>::VEC) {
+    float o[8] = {v[0], v[1], v[2], 0.f, 0.f, 0.f, 0.f, 0.f};
+    *(u32x4*)dst = Elt<T>::pack(o);
+    return;
+  }
   for (int c = 0; c < Cp; ++c) Elt<T>::st(dst + c * Elt<T>::ES, c < 3 ? v[c] : 0.f);
 }
 
