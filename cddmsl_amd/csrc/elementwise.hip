@@ -295,6 +295,120 @@ __global__ __launch_bounds__(256) void k_attn_tokens_bwd(const char* __restrict_
   }
 }
 
+// Softmax glue of the reassociated attention pool (layers.py::AttnPoolFn), one thread per (region, head) row of <= TP scores:
+// forward  p = softmax(S[:P1] * scale) (f32, saved) and its transposed compute-dtype copy pT[k][t][h] (zero for t >= P1);
+// backward ds = p * (dP - sum_t p dP) * scale, written as dsT[k][t][h] and, stacked under p, as pds[k][h | H+h][t] (zero pads).
+template <typename T>
+__global__ void k_attnpool_softmax_fwd(const float* S, float* p, char* pT, long rows, int H, int P1, int TP, float scale) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;     // r = k * H + h
+  if (r >= rows) return;
+  const long k = r / H; const int h = (int)(r - k * H);
+  const float* s = S + r * TP;
+  float mx = -INFINITY;
+  for (int t = 0; t < P1; ++t) mx = fmaxf(mx, s[t] * scale);
+  float sum = 0.f;
+  for (int t = 0; t < P1; ++t) sum += expf(s[t] * scale - mx);
+  const float inv = 1.f / sum;
+  for (int t = 0; t < TP; ++t) {
+    float v = 0.f;
+    if (t < P1) { v = expf(s[t] * scale - mx) * inv; p[r * P1 + t] = v; }
+    Elt<T>::st(pT + ((k * TP + t) * H + h) * Elt<T>::ES, v);
+  }
+}
+template <typename T>
+__global__ void k_attnpool_softmax_bwd(const float* p, const float* dP, char* dsT, char* pds, long rows, int H, int P1, int TP,
+                                       float scale) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const long k = r / H; const int h = (int)(r - k * H);
+  const float* pr = p + r * P1;
+  const float* dp = dP + r * TP;
+  float dot = 0.f;
+  for (int t = 0; t < P1; ++t) dot += pr[t] * dp[t];
+  char* prow = pds + ((k * 2 * H + h) * TP) * Elt<T>::ES;
+  char* drow = pds + ((k * 2 * H + H + h) * TP) * Elt<T>::ES;
+  for (int t = 0; t < TP; ++t) {
+    float pv = 0.f, ds = 0.f;
+    if (t < P1) { pv = pr[t]; ds = pv * (dp[t] - dot) * scale; }
+    Elt<T>::st(dsT + ((k * TP + t) * H + h) * Elt<T>::ES, ds);
+    Elt<T>::st(prow + t * Elt<T>::ES, pv);
+    Elt<T>::st(drow + t * Elt<T>::ES, ds);
+  }
+}
+
+// The same with one WAVE per region (H <= 32 heads, TP <= 64 token slots): lane t holds column t of every head's row, so the
+// score rows are read coalesced, the row reductions are wave reductions, and the transposed outputs leave as H consecutive
+// elements per lane (the one-thread-per-row form above walks 224-byte-strided rows: 1.7 ms/step against 0.1 here).
+template <typename T>
+__global__ __launch_bounds__(256) void k_attnpool_softmax_fwd_w(const float* __restrict__ S, float* __restrict__ p, char* __restrict__ pT,
+                                                                long K, int H, int P1, int TP, float scale) {
+  const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = threadIdx.x & 63;
+  if (k >= K) return;
+  float v[32];
+#pragma unroll
+  for (int h = 0; h < 32; ++h) {
+    v[h] = 0.f;
+    if (h < H) {
+      const bool in = t < P1;
+      const float x = in ? S[(k * H + h) * TP + t] * scale : -INFINITY;
+      const float mx = wave_max(x);
+      const float e = in ? expf(x - mx) : 0.f;
+      const float sum = wave_sum(e);
+      v[h] = e * (1.f / sum);
+      if (in) p[(k * H + h) * P1 + t] = v[h];
+    }
+  }
+  if (t < TP) {
+    char* dst = pT + ((k * TP + t) * H) * Elt<T>::ES;
+    if (H % Elt<T>::VEC == 0) {                    // H consecutive elements of this lane: 16-byte stores
+#pragma unroll
+      for (int g = 0; g < 32 / Elt<T>::VEC; ++g)
+        if (g * Elt<T>::VEC < H) ((u32x4*)dst)[g] = Elt<T>::pack(v + g * Elt<T>::VEC);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 32; ++h)
+        if (h < H) Elt<T>::st(dst + h * Elt<T>::ES, v[h]);
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_attnpool_softmax_bwd_w(const float* __restrict__ p, const float* __restrict__ dP,
+                                                                char* __restrict__ dsT, char* __restrict__ pds, long K, int H, int P1,
+                                                                int TP, float scale) {
+  const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = threadIdx.x & 63;
+  if (k >= K) return;
+  float dsv[32];
+#pragma unroll
+  for (int h = 0; h < 32; ++h) {
+    dsv[h] = 0.f;
+    if (h < H) {
+      const bool in = t < P1;
+      const float pv = in ? p[(k * H + h) * P1 + t] : 0.f;
+      const float dp = in ? dP[(k * H + h) * TP + t] : 0.f;
+      const float dot = wave_sum(pv * dp);
+      dsv[h] = in ? pv * (dp - dot) * scale : 0.f;
+      if (t < TP) {
+        Elt<T>::st(pds + ((k * 2 * H + h) * TP + t) * Elt<T>::ES, pv);
+        Elt<T>::st(pds + ((k * 2 * H + H + h) * TP + t) * Elt<T>::ES, dsv[h]);
+      }
+    }
+  }
+  if (t < TP) {
+    char* dst = dsT + ((k * TP + t) * H) * Elt<T>::ES;
+    if (H % Elt<T>::VEC == 0) {
+#pragma unroll
+      for (int g = 0; g < 32 / Elt<T>::VEC; ++g)
+        if (g * Elt<T>::VEC < H) ((u32x4*)dst)[g] = Elt<T>::pack(dsv + g * Elt<T>::VEC);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 32; ++h)
+        if (h < H) Elt<T>::st(dst + h * Elt<T>::ES, dsv[h]);
+    }
+  }
+}
+
 // ReLU backward: dx = g where y > 0 else 0 (optionally g given in f32 while y/dx are T)
 template <typename T>
 __global__ void k_relu_bwd(const char* g, const char* y, char* dx, long nchunks, int g_f32) {
@@ -534,6 +648,31 @@ extern "C" int cddmsl_attn_tokens_bwd(const void* dtok, const void* relu_mask, v
   while ((K + slab - 1) / slab > 65535) slab *= 2;
   dim3 grid((unsigned)((cch + 255) / 256), (unsigned)(P + 1), (unsigned)((K + slab - 1) / slab));
   DISPATCH(dtype, k_attn_tokens_bwd, <<<grid, dim3(256), 0, (hipStream_t)stream>>>((const char*)dtok, (const char*)relu_mask, (char*)dx, gpos, K, P, TP, cch, slab));
+  return launch_status();
+}
+
+extern "C" int cddmsl_attnpool_softmax_fwd(const float* S, float* p, void* pT, long K, int H, int P1, int TP, float scale, int dtype,
+                                           void* stream) {
+  if (K < 0 || H <= 0 || P1 <= 0 || TP < P1) return CDDMSL_ERR_ARG;
+  const long rows = K * H;
+  if (rows == 0) return CDDMSL_OK;
+  if (H <= 32 && TP <= 64) {
+    DISPATCH(dtype, k_attnpool_softmax_fwd_w, <<<dim3((unsigned)((K + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(S, p, (char*)pT, K, H, P1, TP, scale));
+    return launch_status();
+  }
+  DISPATCH(dtype, k_attnpool_softmax_fwd, <<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(S, p, (char*)pT, rows, H, P1, TP, scale));
+  return launch_status();
+}
+extern "C" int cddmsl_attnpool_softmax_bwd(const float* p, const float* dP, void* dsT, void* pds, long K, int H, int P1, int TP,
+                                           float scale, int dtype, void* stream) {
+  if (K < 0 || H <= 0 || P1 <= 0 || TP < P1) return CDDMSL_ERR_ARG;
+  const long rows = K * H;
+  if (rows == 0) return CDDMSL_OK;
+  if (H <= 32 && TP <= 64) {
+    DISPATCH(dtype, k_attnpool_softmax_bwd_w, <<<dim3((unsigned)((K + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(p, dP, (char*)dsT, (char*)pds, K, H, P1, TP, scale));
+    return launch_status();
+  }
+  DISPATCH(dtype, k_attnpool_softmax_bwd, <<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(p, dP, (char*)dsT, (char*)pds, rows, H, P1, TP, scale));
   return launch_status();
 }
 

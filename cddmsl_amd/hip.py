@@ -36,6 +36,8 @@ def _L():
         L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_attn_tokens_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
         L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
+        L.cddmsl_attnpool_softmax_fwd.argtypes = [vp] * 3 + [c_long, ci, ci, ci, cf, ci, vp]
+        L.cddmsl_attnpool_softmax_bwd.argtypes = [vp] * 4 + [c_long, ci, ci, ci, cf, ci, vp]
         L.cddmsl_gemm_nt_batched.argtypes = [vp] * 4 + [ci] * 7 + [c_long] * 3 + [ci, ci, vp]
         L.cddmsl_gemm_tn_batched.argtypes = [vp] * 3 + [ci] * 7 + [c_long] * 3 + [ci, ci, vp]
         L.cddmsl_relu_bwd.argtypes = [vp, vp, vp, c_long, ci, ci, vp]
@@ -344,6 +346,31 @@ def attn_tokens_bwd(dtok, P, relu_mask=None, gpos=None, want_dx=True):
     dx = torch.empty((K, P, C), device=dtok.device, dtype=dtok.dtype) if want_dx else None
     check(_L().cddmsl_attn_tokens_bwd(ptr(dtok), ptr(relu_mask), ptr(dx), ptr(gpos), K, P, TP, C, _dt(dtok), stream_ptr()), "cddmsl_attn_tokens_bwd")
     return dx
+
+
+@_timed("attnpool_softmax")
+def attnpool_softmax_fwd(S, P1, scale, dtype):
+    """S [K,H,TP] f32 -> (p [K,H,P1] f32 = softmax(S[..., :P1] * scale), pT [K,TP,H] dtype with zero rows past P1)"""
+    require_cuda(S)
+    K, H, TP = S.shape
+    assert S.dtype == torch.float32 and S.is_contiguous() and P1 <= TP
+    p = torch.empty((K, H, P1), device=S.device, dtype=torch.float32)
+    pT = torch.empty((K, TP, H), device=S.device, dtype=dtype)
+    check(_L().cddmsl_attnpool_softmax_fwd(ptr(S), ptr(p), ptr(pT), K, H, P1, TP, float(scale), DT[dtype], stream_ptr()), "cddmsl_attnpool_softmax_fwd")
+    return p, pT
+
+
+@_timed("attnpool_softmax")
+def attnpool_softmax_bwd(p, dP, scale, dtype):
+    """p [K,H,P1] f32, dP [K,H,TP] f32 -> (dsT [K,TP,H], pds [K,2H,TP] = [p ; ds]) in dtype, zero past P1"""
+    require_cuda(p, dP)
+    K, H, P1 = p.shape
+    TP = dP.shape[2]
+    assert p.dtype == dP.dtype == torch.float32 and p.is_contiguous() and dP.is_contiguous() and dP.shape[:2] == (K, H)
+    dsT = torch.empty((K, TP, H), device=p.device, dtype=dtype)
+    pds = torch.empty((K, 2 * H, TP), device=p.device, dtype=dtype)
+    check(_L().cddmsl_attnpool_softmax_bwd(ptr(p), ptr(dP), ptr(dsT), ptr(pds), K, H, P1, TP, float(scale), DT[dtype], stream_ptr()), "cddmsl_attnpool_softmax_bwd")
+    return dsT, pds
 
 
 def _eptr(t, elem_offset=0):

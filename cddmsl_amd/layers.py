@@ -469,9 +469,7 @@ class AttnPoolFn(torch.autograd.Function):
         # S[k] = U[k] (H x C) . tok[k]^T (C x TP)
         S = torch.empty((K, H, TP), device=dev, dtype=torch.float32)
         hip.gemm_nt_batched(zu, tok, S, H, TP, C, C, C, TP, K, 2 * H * C, TP * C, H * TP, a_off=H * C)
-        p = torch.softmax(S[:, :, :P + 1] * (D ** -0.5), dim=-1)                              # [K,H,P+1] f32
-        pT = torch.zeros((K, TP, H), device=dev, dtype=T)
-        pT[:, :P + 1] = p.transpose(1, 2)
+        p, pT = hip.attnpool_softmax_fwd(S, P + 1, D ** -0.5, T)                              # [K,H,P+1] f32 ; [K,TP,H] T
         # Z[k] (H x C) = P[k] (H x TP) . tok[k] (TP x C)      (reduction over token rows)
         z = torch.empty((K, H, C), device=dev, dtype=T)
         hip.gemm_tn_batched(pT, tok, z, TP, H, C, H, C, C, K, TP * H, TP * C, H * C)
@@ -512,17 +510,12 @@ class AttnPoolFn(torch.autograd.Function):
         # dP[k] = dZ[k] . tok[k]^T ; softmax backward in fp32
         dP = torch.empty((K, H, TP), device=dev, dtype=torch.float32)
         hip.gemm_nt_batched(zu, tok, dP, H, TP, C, C, C, TP, K, 2 * H * C, TP * C, H * TP)
-        dp = dP[:, :, :P + 1]
-        ds = p * (dp - (p * dp).sum(dim=-1, keepdim=True)) * (D ** -0.5)                    # [K,H,P+1] f32
+        # ds = p * (dp - sum p dp) * scale, as dsT [K,TP,H] and stacked under p as pds [K,2H,TP] (one kernel)
+        dsT, pds = hip.attnpool_softmax_bwd(p, dP, D ** -0.5, T)
         # dU[k] (H x C) = dS[k] (H x TP) . tok[k]
-        dsT = torch.zeros((K, TP, H), device=dev, dtype=T)
-        dsT[:, :P + 1] = ds.transpose(1, 2)
         du = torch.empty((K, H, C), device=dev, dtype=T)
         hip.gemm_tn_batched(dsT, tok, du, TP, H, C, H, C, C, K, TP * H, TP * C, H * C)
         # dtok[k] (TP x C) = [P[k]; dS[k]]^T (TP x 2H) . [dZ[k]; U[k]] (2H x C)     (reduction over the 2H stacked rows)
-        pds = torch.zeros((K, 2 * H, TP), device=dev, dtype=T)
-        pds[:, :H, :P + 1] = p
-        pds[:, H:, :P + 1] = ds
         dtok = torch.empty((K, TP, C), device=dev, dtype=T)
         hip.gemm_tn_batched(pds, zu, dtok, 2 * H, TP, C, TP, C, C, K, 2 * H * TP, 2 * H * C, TP * C)
         # dq0[k, hD:(h+1)D] = dU[k,h,:] @ Wk[hD:(h+1)D, :]^T

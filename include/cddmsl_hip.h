@@ -108,6 +108,12 @@ int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, in
  * (atomics) the positional embedding's gradient sum_k dtok[k][t][:] in the same pass; dx may be NULL when only gpos is wanted */
 int cddmsl_attn_tokens_bwd(const void* dtok, const void* relu_mask, void* dx, float* gpos, int K, int P, int TP, int C, int dtype,
                            void* stream);
+/* softmax of the query-0 scores (clip_backbone.py:95-105, F.multi_head_attention_forward's softmax over the 50 keys) between the
+ * batched products: S [K][H][TP] f32 -> p [K][H][P1] f32 = softmax(S[..., :P1] * scale) and pT [K][TP][H] (dtype; zero rows past
+ * P1).  Backward: ds = p * (dP - sum p dP) * scale -> dsT [K][TP][H] and pds [K][2H][TP] = [p ; ds] (dtype; zero columns past P1) */
+int cddmsl_attnpool_softmax_fwd(const float* S, float* p, void* pT, long K, int H, int P1, int TP, float scale, int dtype, void* stream);
+int cddmsl_attnpool_softmax_bwd(const float* p, const float* dP, void* dsT, void* pds, long K, int H, int P1, int TP, float scale,
+                                int dtype, void* stream);
 
 /* ---- fused multi-head attention for short sequences: the ClipCap mapper's softmax(QK^T * scale) V (no mask), 80 tokens x 8
  * heads of 96 (modeling/backbone/clipcap/clipcap.py:59-83).  bf16 only (dtype 0), dh == 96, t <= 96; element (s, i, h, c) of

@@ -494,3 +494,31 @@ def test_layernorm_kernels_all_widths(D, dtype):
     out = hip.layernorm_bwd(dy, x, gam, mean, rstd, accumulate_into=acc)
     assert out.data_ptr() == acc.data_ptr()
     assert float((acc - (skip + xr.grad)).abs().max()) < 2e-5 * max(1.0, float(xr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("H", [32, 40])          # one wave per region (H <= 32) / one thread per row
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attnpool_softmax_glue(dtype, H):
+    """Softmax over the 50 keys of the query-0 attention pool and its backward, in the padded / transposed layouts the
+    batched products read (clip_backbone.py:95-105) -- vs torch.softmax and its autograd."""
+    from cddmsl_amd import hip
+    K, P1, TP = 77, 50, 56
+    g = torch.Generator().manual_seed(5)
+    S = (torch.randn(K, H, TP, generator=g) * 3).cuda()
+    dP = torch.randn(K, H, TP, generator=g).cuda()
+    scale = 64 ** -0.5
+    p, pT = hip.attnpool_softmax_fwd(S, P1, scale, dtype)
+    Sr = S[:, :, :P1].clone().requires_grad_(True)
+    ref = torch.softmax(Sr * scale, dim=-1)
+    assert float((p - ref.detach()).abs().max()) < 1e-6
+    want_pT = torch.zeros(K, TP, H, device="cuda", dtype=dtype)
+    want_pT[:, :P1] = p.transpose(1, 2)
+    assert torch.equal(pT, want_pT)
+    (ref * dP[:, :, :P1]).sum().backward()
+    dsT, pds = hip.attnpool_softmax_bwd(p, dP, scale, dtype)
+    ds = Sr.grad                                               # d/dS of sum(softmax(S * scale) * dP)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert float((dsT[:, :P1].float() - ds.transpose(1, 2)).abs().max()) < tol * max(1.0, float(ds.abs().max()))
+    assert float(dsT[:, P1:].abs().max()) == 0.0
+    assert torch.equal(pds[:, :H, :P1], p.to(dtype)) and torch.equal(pds[:, H:, :P1], dsT[:, :P1].transpose(1, 2))
+    assert float(pds[:, :, P1:].abs().max()) == 0.0
