@@ -81,6 +81,30 @@ __global__ void k_cosine_logits_bwd(const float* ds, const float* x, const float
   const float* xr = x + r * D;
   float iv = inv[r];
   float dot = 0.f;
+  if (D <= 64 * 16) {                     // the row's g values stay in registers (same sums, formed once instead of twice)
+    float gv[16], xv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int d = lane + 64 * i;
+      gv[i] = 0.f; xv[i] = 0.f;
+      if (d < D) {
+        float g = 0.f;
+        for (int c = 0; c < Kc; ++c) g += ds[r * (Kc + 1) + c] * invT * wn[(long)c * D + d];
+        gv[i] = g; xv[i] = xr[d] * iv;
+        dot += g * xv[i];
+      }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) {
+        float v = iv * (gv[i] - xv[i] * dot);
+        dx[r * D + d] = accumulate ? dx[r * D + d] + v : v;
+      }
+    }
+    return;
+  }
   for (int d = lane; d < D; d += 64) {
     float g = 0.f;
     for (int c = 0; c < Kc; ++c) g += ds[r * (Kc + 1) + c] * invT * wn[(long)c * D + d];
