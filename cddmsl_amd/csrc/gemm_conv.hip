@@ -47,6 +47,13 @@ static inline FastDiv make_fastdiv(unsigned d) {
 }
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.shr; }
 
+// FrozenBN / bias in the epilogues: v * scale + bias.  The exact-f32 instantiations round twice like the reference's separate
+// multiply and add (this file is built with -ffp-contract=off); the bf16 ones use one fused multiply-add -- one vector-ALU
+// operation less per output element in every epilogue, identical where scale = 1 and bias = 0 (input-gradient launches).
+template <typename T> __device__ __forceinline__ float affine(float v, float sc, float bi) {
+  return sizeof(T) == 2 ? __builtin_fmaf(v, sc, bi) : v * sc + bi;
+}
+
 struct ConvArgs {
   const char* x;
   const char* w;
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_reg(ConvArgs p) {
           f32x4 v0 = src[0], v1 = src[1];
           float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+          for (int j = 0; j < 8; ++j) v[j] = affine<T>(v[j], sc[j], bi[j]);
           if (p.residual) {
             float rv[8];
             load8<T>(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES, rv);
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd_reg(ConvArgs p) {
       for (int g = 0; g < 16; ++g) {
         int m = m0 + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         if (m >= p.M) continue;
-        float v = acc[a][b][g] * sc + bi;
+        float v = affine<T>(acc[a][b][g], sc, bi);
         if (p.residual) v += Mma<T>::load(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES);
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.relu_mask && !(Mma<T>::load(p.relu_mask + ((long)m * p.ldm + n) * Mma<T>::ES) > 0.f)) v = 0.f;
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
           f32x4 v0 = src[0], v1 = src[1];
           float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+          for (int j = 0; j < 8; ++j) v[j] = affine<T>(v[j], sc[j], bi[j]);
           if (p.residual) {
             float rv[8];
             if (rf32) load8<float>(p.residual + ((long)m * p.ldr + n) * 4, rv);
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd(ConvArgs p) {
       for (int g = 0; g < 16; ++g) {
         int m = m0 + wm * 64 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         if (m >= p.M) continue;
-        float v = acc[a][b][g] * sc + bi;
+        float v = affine<T>(acc[a][b][g], sc, bi);
         if (p.residual) v += Mma<T>::load(p.residual + ((long)m * p.ldr + n) * Mma<T>::ES);
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.relu_mask && !(Mma<T>::load(p.relu_mask + ((long)m * p.ldm + n) * Mma<T>::ES) > 0.f)) v = 0.f;
@@ -1604,7 +1611,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
       for (int g = 0; g < 16; ++g) {
         const int mo = tile * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
         if (mo < p.M) {
-          float v = acc[nt][g] * sc[nt] + bi[nt];
+          float v = affine<T>(acc[nt][g], sc[nt], bi[nt]);
           if (p.relu) v = fmaxf(v, 0.f);
           if (p.relu_mask && !(Mma<T>::load(p.relu_mask + ((long)mo * p.ldm + nt * 32 + r) * ES) > 0.f)) v = 0.f;
           Mma<T>::store(p.y + ((long)mo * p.ldy + nt * 32 + r) * ES, v);
@@ -1946,7 +1953,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
       const f32x4 v0 = src[0], v1 = src[1];
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+      for (int j = 0; j < 8; ++j) v[j] = affine<T>(v[j], sc[j], bi[j]);
       if (rf32) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
