@@ -16,6 +16,7 @@ host cores, rank 0 / N=1 only).
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,8 +35,20 @@ def make_cfg(dtype, kd=False):
     return cfg
 
 
-def cpu_baseline(height, width, threads):
-    """Oracle (kind 'port'): one full training step (3 branches + backward + clip/SGD) on ONE image, CPU fp32."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(height, width, threads, batch=2, timed=3, budget_s=150.0):
+    """Oracle (kind 'port') as SURVEY.md 8(d) defines the CPU baseline: the full training step (3 branches + backward +
+    clip/SGD) on B=2 images, CPU fp32, one warm-up step, then the median of ``timed`` steps -- bounded: timing stops
+    early once ``budget_s`` seconds of timed steps are spent (at least one timed step always runs; the sample says how many)."""
     from cddmsl_amd import synthetic
     from oracle import model as om
     torch.set_num_threads(threads)
@@ -45,18 +58,54 @@ def cpu_baseline(height, width, threads):
     keys = om.trainable_keys(sd, cfg)
     for k in keys:
         sd[k].requires_grad_(True)
-    batch = synthetic.make_batch(1, height, width)
-    t0 = time.perf_counter()
-    ld = om.run_step_losses(sd, msd, cfg, batch, 20000, torch.Generator().manual_seed(1))
-    sum(ld.values()).backward()
-    grads = {k: sd[k].grad for k in keys}
-    with torch.no_grad():
-        plain = {k: v.detach() for k, v in sd.items()}
-        om.sgd_step(plain, grads, {}, cfg, 20000)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 image {height}x{width}, 1 full step (3 branches, backward, clip+SGD), oracle fp32 on "
-                      f"{threads} host threads, {dt:.1f} s"}
+    data = synthetic.make_batch(batch, height, width)
+    gen = torch.Generator().manual_seed(1)
+    mom = {}
+
+    def step():
+        for k in keys:
+            sd[k].grad = None
+        t0 = time.perf_counter()
+        ld = om.run_step_losses(sd, msd, cfg, data, 20000, gen)
+        sum(ld.values()).backward()
+        grads = {k: sd[k].grad for k in keys}
+        with torch.no_grad():
+            plain = {k: v.detach() for k, v in sd.items()}
+            om.sgd_step(plain, grads, mom, cfg, 20000)
+        return time.perf_counter() - t0
+
+    warm = step()
+    times = []
+    while len(times) < timed and (not times or sum(times) + times[-1] <= budget_s):
+        times.append(step())
+    med = sorted(times)[len(times) // 2]
+    return {"value": batch / med, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"B={batch} images {height}x{width}, full step (3 branches, backward, clip+SGD), oracle fp32 on "
+                      f"{threads} threads of {cpu_model_name()}; 1 warm-up ({warm:.1f} s) then median of {len(times)} "
+                      f"timed steps ({', '.join('%.1f' % t for t in times)} s)"}
+
+
+def launch_plan(gpus, argv, env, device_count):
+    """engine/launch.py:27-82 for the bench: WHO runs the ranks.
+
+    Returns ("run", None) when this process is itself a rank (or the single-GPU run), ("spawn", cmd) when it has to start
+    ``torch.distributed.run`` with one child per GPU -- decided BEFORE anything touches the GPU, so the parent never holds
+    a HIP context -- and raises SystemExit with a message when the request cannot be met (fewer devices than --gpus, or a
+    launcher-provided WORLD_SIZE that contradicts --gpus).  Pure function of its arguments (tests/test_cabi_host.py)."""
+    gpus = max(int(gpus), 1)
+    if "RANK" in env:
+        world = int(env.get("WORLD_SIZE", "1"))
+        if world != gpus:
+            raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {gpus}: refusing to report a number for the wrong rank count")
+        return "run", None
+    if gpus == 1:
+        return "run", None
+    if not env.get("CDDMSL_SHARE_GPU") and device_count < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} needs {gpus} visible GPUs, this box has {device_count} (one RCCL rank per device)")
+    port = env.get("MASTER_PORT", "29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
 
 
 def main():
@@ -71,11 +120,33 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forward-roofline", action="store_true", help="skip the extra forward-only loop (profiling runs: keeps the kernel mix = the timed steps)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=3, help="timed oracle steps (median reported), after one warm-up")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal: start the ranks, form the process group (gloo when "
+                    "no GPU is visible), barrier, print the rank layout; no model, no timing")
     args = ap.parse_args()
+
+    # one process per GPU: with --gpus N > 1 and no launcher around us, start N ranks as children (before any GPU call)
+    mode, cmd = launch_plan(args.gpus, sys.argv[1:], os.environ, torch.cuda.device_count())
+    if mode == "spawn":
+        sys.exit(subprocess.call(cmd))
 
     from cddmsl_amd import engine, hip
     rank, world = engine.init_distributed()
-    assert world == max(args.gpus, 1) or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: process group has {world} ranks but --gpus {args.gpus}")
+    if args.dry_run:
+        ranks = [None] * world
+        if world > 1:
+            dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+            dist.barrier()
+        else:
+            ranks = [(0, 0)]
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": world, "ranks": ranks,
+                              "dist_backend": dist.get_backend() if world > 1 else None}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     # CDDMSL_SHARE_GPU=1 (rehearsal only): all ranks on device 0 with the gloo backend, to exercise the N>1 code path
     # on a one-GPU box; RCCL itself needs one device per rank.
     dev = torch.device("cuda", 0 if os.environ.get("CDDMSL_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0")))
@@ -146,6 +217,11 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    devs = [torch.cuda.current_device()]
+    if world > 1:
+        dl = [None] * world
+        dist.all_gather_object(dl, torch.cuda.current_device())
+        devs = dl
     losses = {k: float(v.detach()) for k, v in last.items()}
 
     if rank == 0:
@@ -163,7 +239,8 @@ def main():
         peak = 2500.0 if args.dtype == "bf16" else 157.3
         out = {
             "metric": "images/sec (train step) VOC+Clipart RN50-C4", "value": gb * args.steps / dt, "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "rccl_ranks": world, "rank_devices": devs,
+            "dist_backend": (dist.get_backend() if world > 1 else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "faster_rcnn_voc.sh VOC(labeled)+Clipart(unlabeled) CLIP RN50-C4 + caption consistency "
                                    f"(iter>10000: supervised + image-level + region-level), {args.batch} img/GPU "
@@ -190,7 +267,7 @@ def main():
                                        "frac": ftf / (fwd_ms * 1e-3) / peak, "images_per_sec_forward": args.batch / (fwd_ms * 1e-3)}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
-            out["cpu_baseline"] = cpu_baseline(args.height, args.width, threads)
+            out["cpu_baseline"] = cpu_baseline(args.height, args.width, threads, timed=max(args.cpu_baseline_steps, 1))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -725,3 +725,6 @@ extern "C" int cddmsl_sgd_clip_step(float** params, const float** grads, float**
   }
   return launch_status();
 }
+
+// ABI version of include/cddmsl_hip.h (bumped when an entry point's signature changes); 2 = round 2 (bring-up probe removed)
+extern "C" int cddmsl_abi_version() { return 2; }

@@ -161,9 +161,14 @@ def inference_on_dataset(model, data_loader, evaluator):
     return evaluator.evaluate()
 
 
-def run_eval_only(model, cfg, args, rank=0, world=1):
+def run_eval_only(model, cfg, args, rank=0, world=1, return_results=False):
     """tools/train_caption_consistency.py:143-152 (``--eval-only``): VOC-style test set under ``args.voc_root`` -> AP dict
-    printed by rank 0.  Returns the process exit code."""
+    printed by rank 0.  Every rank evaluates its shard of the test set (``world`` has to be the process group's size: the
+    evaluator merges all ranks' detections, so unsharded ranks would count every detection ``world`` times).  Returns the
+    process exit code (or the result dict: rank 0, ``return_results``)."""
+    import torch.distributed as dist
+    ws = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    assert world == ws, f"run_eval_only: world={world} but the process group has {ws} ranks"
     from .data import build_detection_test_loader, load_voc_instances
     dicts = load_voc_instances(args.voc_root, args.voc_split, VOC_CLASS_NAMES[: cfg.MODEL.ROI_HEADS.NUM_CLASSES])
     loader = build_detection_test_loader(cfg, dicts, batch_size=1, rank=rank, world=world, device=cfg.MODEL.DEVICE)
@@ -171,4 +176,4 @@ def run_eval_only(model, cfg, args, rank=0, world=1):
     res = inference_on_dataset(model, loader, ev)
     if rank == 0:
         print({k: round(v, 4) for k, v in res["bbox"].items()})
-    return 0
+    return res if return_results else 0

@@ -22,6 +22,20 @@ def bump_weight_version():
     _STEP[0] += 1
 
 
+_LOAD_GEN = [0]  # bumped whenever a state dict is loaded into a module of this package: caches of DERIVED tensors (folded
+#                  FrozenBN affines, padded stem weights, block-parameter tuples) key on it; caches of prepared parameter
+#                  copies additionally key on the parameter's ``_version`` (load_state_dict copies in place: same data_ptr)
+
+
+def note_weights_loaded(*_):
+    _LOAD_GEN[0] += 1
+    _STEP[0] += 1
+
+
+def load_generation():
+    return _LOAD_GEN[0]
+
+
 _TOUCHED = set()   # ids of parameters that received a gradient this step (SGD skips grad-less parameters)
 
 
@@ -73,7 +87,7 @@ class PreparedWeight:
     def _refresh_all(dtype):
         """one launch for every trainable weight that has buffers of this dtype and was used last step"""
         items = [pw for pw in PreparedWeight._live if pw._wf is not None and pw._dtype == dtype and pw._used
-                 and pw._key is not None and pw._key[2] == pw.param.data_ptr()]
+                 and pw._key is not None and pw._key[2:] == (pw.param.data_ptr(), pw.param._version)]
         if not items:
             return
         sig = tuple(pw._sig() for pw in items)
@@ -86,11 +100,11 @@ class PreparedWeight:
             PreparedWeight._table = (sig, to_device_async(torch.tensor(rows, dtype=torch.int64), items[0].param.device), dtype)
         hip.weight_prep_multi(PreparedWeight._table[1], len(items), dtype)
         for pw in items:
-            pw._key = (dtype, _STEP[0], pw.param.data_ptr())
+            pw._key = (dtype, _STEP[0], pw.param.data_ptr(), pw.param._version)
             pw._used = False
 
     def get(self, dtype, need_dgrad=True):
-        key = (dtype, -1 if self.frozen else _STEP[0], self.param.data_ptr())
+        key = (dtype, -1 if self.frozen else _STEP[0], self.param.data_ptr(), self.param._version)
         if key != self._key and not self.frozen and self._wf is not None and self._dtype == dtype:
             PreparedWeight._refresh_all(dtype)        # first stale weight of the step: bring every registered weight up to date
         if key != self._key or (need_dgrad and self._wd is None):

@@ -58,6 +58,7 @@ class FrozenBatchNorm2d(nn.Module):
 
     def _load_from_state_dict(self, *a, **k):
         self._aff = None
+        layers.note_weights_loaded()          # derived caches above this module (block params, prepared weights) are stale
         return super()._load_from_state_dict(*a, **k)
 
 
@@ -92,7 +93,7 @@ class ResStage(nn.Sequential):
         self._bp = None
 
     def block_params(self):
-        dev = self[0].conv1.weight.device
+        dev = (self[0].conv1.weight.device, layers.load_generation())
         if self._bp is None or self._bp[0] != dev:
             self._bp = (dev, [b.params() for b in self])
         return self._bp[1]
@@ -187,7 +188,7 @@ class ModifiedResNet(nn.Module):
     # ------------------------------------------------------------------ forward
     def _stem_weights(self, T, cp):
         dev = self.conv1.weight.device
-        key = (T, cp, dev)
+        key = (T, cp, dev, layers.load_generation(), self.conv1.weight._version, self.conv2.weight._version, self.conv3.weight._version)
         if self._stem_w is None or self._stem_w[0] != key:
             w1 = torch.zeros(self.conv1.weight.shape[0], 3, 3, cp, device=dev)
             w1[..., :3] = self.conv1.weight.detach().permute(0, 2, 3, 1)

@@ -36,7 +36,7 @@ class BottleneckBlock(nn.Module):
         self._pw = None
 
     def prepared(self):
-        dev = self.conv1.weight.device
+        dev = (self.conv1.weight.device, layers.load_generation())
         if self._pw is None or self._pw[0] != (dev, self.frozen):
             mods = (self.conv1, self.conv2, self.conv3, self.shortcut)
             aff = tuple(None if m is None else m.norm.affine() for m in mods)
@@ -133,7 +133,7 @@ class BasicStem(nn.Module):
 
     def forward_nhwc(self, x):
         T, cp = x.dtype, x.shape[-1]
-        key = (T, cp, self.conv1.weight.device)
+        key = (T, cp, self.conv1.weight.device, layers.load_generation(), self.conv1.weight._version)
         if self._w is None or self._w[0] != key:
             w = torch.zeros(self.conv1.weight.shape[0], 7, 7, cp, device=x.device)
             w[..., :3] = self.conv1.weight.detach().permute(0, 2, 3, 1)

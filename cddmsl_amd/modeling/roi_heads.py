@@ -62,21 +62,38 @@ class _Linear(nn.Module):
 NMS_MAX_CANDIDATES = 12288      # cddmsl_nms handles 192 mask words of 64 boxes per image
 
 
+def _nms_sorted(boxes, scores, iou_threshold):
+    """torchvision.ops.nms on the HIP kernels: kept indices in descending-score order.  More candidates than the kernel's
+    mask holds is an error (the C-ABI returns CDDMSL_ERR_ARG for it) -- never a silent truncation."""
+    n = boxes.shape[0]
+    if n > NMS_MAX_CANDIDATES:
+        raise ValueError(f"nms: {n} candidates in one group exceed the kernel's limit of {NMS_MAX_CANDIDATES}")
+    keys, order = hip.sort_desc(scores.float().contiguous().view(1, n))
+    order = order[0].long()
+    sorted_boxes = boxes[order].view(1, n, 4).contiguous()
+    keep, nkeep = hip.nms(sorted_boxes, torch.ones((1, n), dtype=torch.uint8, device=boxes.device), float(iou_threshold), n)
+    return order[keep[0, : int(nkeep[0])].long()]
+
+
 def batched_nms(boxes, scores, idxs, iou_threshold):
-    """layers/nms.py:19-39 -> torchvision.ops.batched_nms: per-category NMS through the coordinate-offset trick, on the HIP
-    sort + bit-mask NMS kernels.  Returns kept indices in descending-score order.  (More than 12 288 candidates per image
-    -- the kernel's limit -- would keep only the 12 288 highest-scoring ones; thresholded detections never get there.)"""
+    """layers/nms.py:19-39 -> torchvision.ops.batched_nms: per-category NMS, on the HIP sort + bit-mask NMS kernels.  Returns
+    kept indices in descending-score order.  Up to 12 288 candidates: ONE pass through the coordinate-offset trick
+    (torchvision's ``_batched_nms_coordinate_trick``); beyond that -- more than the kernel's mask words hold -- one pass per
+    category (torchvision's ``_batched_nms_vanilla``, which it also switches to for large inputs); a single category with more
+    than 12 288 candidates raises."""
     n = boxes.shape[0]
     if n == 0:
         return torch.empty(0, dtype=torch.int64, device=boxes.device)
     boxes = boxes.float()
-    off = idxs.to(boxes) * (boxes.max() + 1.0)
-    keys, order = hip.sort_desc(scores.float().contiguous().view(1, n))
-    order = order[0].long()[:NMS_MAX_CANDIDATES]
-    m = order.numel()
-    sorted_boxes = (boxes + off[:, None])[order].view(1, m, 4).contiguous()
-    keep, nkeep = hip.nms(sorted_boxes, torch.ones((1, m), dtype=torch.uint8, device=boxes.device), float(iou_threshold), m)
-    return order[keep[0, : int(nkeep[0])].long()]
+    if n <= NMS_MAX_CANDIDATES:
+        off = idxs.to(boxes) * (boxes.max() + 1.0)
+        return _nms_sorted(boxes + off[:, None], scores, iou_threshold)
+    keep_mask = torch.zeros(n, dtype=torch.bool, device=boxes.device)
+    for c in torch.unique(idxs).tolist():
+        sel = torch.nonzero(idxs == c).squeeze(1)
+        keep_mask[sel[_nms_sorted(boxes[sel], scores[sel], iou_threshold)]] = True
+    ki = torch.nonzero(keep_mask).squeeze(1)
+    return ki[scores[ki].sort(descending=True, stable=True)[1]]
 
 
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):

@@ -27,8 +27,11 @@ class ClippedSGD:
         self.cfg = cfg
         self.momentum, self.wd = s.MOMENTUM, s.WEIGHT_DECAY
         cg = s.CLIP_GRADIENTS
-        assert cg.ENABLED and cg.CLIP_TYPE == "norm" and cg.NORM_TYPE == 2.0, "hot path = per-parameter L2-norm clipping"
-        self.clip = cg.CLIP_VALUE
+        if cg.ENABLED:
+            assert cg.CLIP_TYPE == "norm" and cg.NORM_TYPE == 2.0, "hot path = per-parameter L2-norm clipping (solver/build.py:59-67)"
+            self.clip = cg.CLIP_VALUE
+        else:       # solver/build.py:113-130 builds plain torch.optim.SGD (stock config #1): an infinite clip value = factor 1
+            self.clip = float("inf")
         self.moms = None
         self.norm_ws = None
         self.steps_done = 0

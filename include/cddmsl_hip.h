@@ -26,7 +26,6 @@ extern "C" {
 #endif
 
 int cddmsl_abi_version(void);
-int cddmsl_probe_axpb(const float* x, float* y, float a, float b, long n, void* stream);
 
 /* ---- implicit-GEMM convolution / linear (bf16 or exact-f32 MFMA) ----------------------------------------------
  * replaces ATen conv2d / F.linear + FrozenBatchNorm2d + ReLU (+ residual add, + AvgPool2d) as called from

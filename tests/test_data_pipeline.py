@@ -141,3 +141,51 @@ def test_checkpoint_roundtrip_and_side_loads(tmp_path):
     assert t.iter == 42 and not inc2.unexpected_keys and not inc2.incorrect_shapes and os.path.basename(p2) == "model_0000041.pth"
     for k, v in model.state_dict().items():
         assert torch.equal(v, model2.state_dict()[k]), k
+
+
+def test_clip_checkpoint_name_conversion(tmp_path):
+    """checkpoint/clip_model_loading.py:10-343 on a synthetic state dict: an OpenAI-CLIP-style file (``visual.*`` tower + text
+    tower) converts to the model's ``backbone.*`` names (never ``offline_backbone.*``), the offline-module checkpoint
+    (bb_rpn_weights) to ``offline_backbone.*``; Caffe2-layout box-head rows are re-ordered; round trip through a file."""
+    from cddmsl_amd import synthetic
+    from cddmsl_amd.checkpoint import DetectionCheckpointer, convert_clip_state
+    from cddmsl_amd.modeling import build_model
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "VOC-Experiments", "faster_rcnn_CLIP_R_50_C4.yaml"))
+    cfg.MODEL.DEVICE = "cpu"
+    model = build_model(cfg)
+    sd = synthetic.make_state_dict(0)
+    bb = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    oai = {"visual." + k: v for k, v in bb.items()}
+    oai.update({"transformer.resblocks.0.attn.in_proj_weight": torch.zeros(4, 4), "token_embedding.weight": torch.zeros(5, 4),
+                "logit_scale": torch.tensor(4.6)})
+    own = model.state_dict()
+    conv, pairs = convert_clip_state(own, oai)
+    assert all(("backbone." + k) in conv and torch.equal(conv["backbone." + k], v) for k, v in bb.items())
+    assert not any(k.startswith("offline_backbone.") for k in conv)
+    assert pairs["backbone.layer3.0.downsample.0.weight"] == "visual.layer3.0.downsample.0.weight"
+    assert {"transformer.resblocks.0.attn.in_proj_weight", "token_embedding.weight", "logit_scale"} <= set(conv)   # passed through
+    # through a file named like the published one
+    path = str(tmp_path / "OAI_CLIP_RN50.pth")
+    torch.save(oai, path)
+    model.backbone.layer2[0].conv1.weight.data.zero_()
+    inc = DetectionCheckpointer(model, str(tmp_path)).load(path)
+    assert sorted(inc.unexpected_keys) == ["logit_scale", "token_embedding.weight", "transformer.resblocks.0.attn.in_proj_weight"]
+    assert not [k for k in inc.missing_keys if k.startswith("backbone.")] and not inc.incorrect_shapes
+    assert torch.equal(model.state_dict()["backbone.layer2.0.conv1.weight"], sd["backbone.layer2.0.conv1.weight"])
+    # second checkpoint -> offline modules only
+    second = {"backbone.layer1.0.conv1.weight": sd["backbone.layer1.0.conv1.weight"] + 1.0,
+              "proposal_generator.rpn_head.conv.weight": sd["proposal_generator.rpn_head.conv.weight"], "roi_heads.x": torch.zeros(1)}
+    conv2, _ = convert_clip_state(own, second, bb_rpn_weights=True)
+    assert set(conv2) == {"offline_backbone.layer1.0.conv1.weight", "offline_proposal_generator.rpn_head.conv.weight"}
+    # Caffe2-layout heads: bbox_pred drops the 4 background rows, cls_score moves the background row last; shape mismatch skips
+    heads = {"bbox.pred.w": torch.arange(84.0 * 2).view(84, 2), "cls.score.w": torch.arange(21.0).view(21, 1), "conv.rpn.w": torch.zeros(3)}
+    tgt = {"roi_heads.box_predictor.bbox_pred.w": torch.zeros(80, 2), "roi_heads.box_predictor.cls_score.w": torch.zeros(21, 1),
+           "proposal_generator.rpn_head.conv.w": torch.zeros(4)}
+    conv3, pairs3 = convert_clip_state(tgt, heads)
+    assert torch.equal(conv3["roi_heads.box_predictor.bbox_pred.w"], heads["bbox.pred.w"][4:])
+    assert conv3["roi_heads.box_predictor.cls_score.w"].flatten().tolist() == list(range(1, 21)) + [0]
+    assert "proposal_generator.rpn_head.conv.w" in conv3 and "proposal_generator.rpn_head.conv.w" not in pairs3   # shape mismatch: unmatched
+    # one checkpoint tensor claimed by two model keys is an error
+    with pytest.raises(ValueError):
+        convert_clip_state({"a.conv1.weight": torch.zeros(1), "b.conv1.weight": torch.zeros(1)}, {"conv1.weight": torch.zeros(1)})

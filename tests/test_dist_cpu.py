@@ -59,3 +59,110 @@ def test_world2_gloo():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert len(ret) == 2 and abs(ret[0] - ret[1]) < 1e-6   # every rank computes the same full-matrix loss
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N: who starts the ranks (engine/launch.py:27-82 of the reference spawns one process per GPU itself)
+def _bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launch_plan():
+    b = _bench()
+    assert b.launch_plan(1, [], {}, 0) == ("run", None)
+    # under a launcher: WORLD_SIZE has to equal --gpus, there is no "world == 1" escape
+    assert b.launch_plan(4, [], {"RANK": "2", "WORLD_SIZE": "4"}, 8) == ("run", None)
+    with pytest.raises(SystemExit):
+        b.launch_plan(8, [], {"RANK": "0", "WORLD_SIZE": "1"}, 8)
+    with pytest.raises(SystemExit):
+        b.launch_plan(1, [], {"RANK": "0", "WORLD_SIZE": "2"}, 8)
+    # no launcher: spawn N ranks; refuse when the box has fewer devices
+    mode, cmd = b.launch_plan(8, ["--gpus", "8", "--steps", "5"], {"MASTER_PORT": "29999"}, 8)
+    assert mode == "spawn" and cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    with pytest.raises(SystemExit) as e:
+        b.launch_plan(2, [], {}, 1)
+    assert "needs 2 visible GPUs" in str(e.value)
+
+
+def test_bench_gpus2_without_devices_exits_nonzero():
+    """`python bench.py --gpus 2` on a box with fewer than 2 devices: non-zero exit and a message, never an n_gpus: 1 line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CDDMSL_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "visible GPUs" in r.stderr
+
+
+def test_bench_spawns_two_ranks_dry_run():
+    """The spawn path end to end (rehearsal: CDDMSL_SHARE_GPU lifts the device-count check, gloo because no GPU here):
+    bench.py --gpus 2 --dry-run starts torch.distributed.run itself, both ranks join, rank 0 reports 2 ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(CDDMSL_SHARE_GPU="1", MASTER_PORT=str(_free_port()), CDDMSL_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and sorted(x[0] for x in out["ranks"]) == [0, 1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# --eval-only over several ranks: InferenceSampler-style sharding + gather of the predictions (evaluation/evaluator.py:103,
+# pascal_voc_evaluation.py:79): a 2-rank evaluation gives the 1-rank result
+class _ToyDetector(torch.nn.Module):
+    def forward(self, batched_inputs):
+        from cddmsl_amd.structures import Boxes, Instances
+        out = []
+        for x in batched_inputs:
+            h, w = x["image"].shape[-2:]
+            i = int(x["image_id"])                      # _make_voc: object k of image i = class (i + k) % 20 at (5+7k, 3+5k, 40+9k, 50+4k)
+            boxes = torch.tensor([[4.0, 2.0, 40.0, 50.0], [1.0, 1.0, w / 2.0, h / 2.0]])
+            out.append({"instances": Instances((h, w), pred_boxes=Boxes(boxes), scores=torch.tensor([0.9 - 0.01 * i, 0.3 + 0.02 * i]),
+                                               pred_classes=torch.tensor([i % 20, (i + 3) % 20]))})
+        return out
+
+
+def _eval_worker(rank, world, port, root, ret):
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import argparse
+        from cddmsl_amd import evaluation
+        from cddmsl_amd.config import get_cfg
+        cfg = get_cfg()
+        cfg.merge_from_list(["MODEL.DEVICE", "cpu", "INPUT.MIN_SIZE_TEST", 0])
+        args = argparse.Namespace(voc_root=root, voc_split="test", voc_year=2007)
+        res = evaluation.run_eval_only(_ToyDetector(), cfg, args, rank, world, return_results=True)
+        if rank == 0:
+            ret["w%d" % world] = dict(res["bbox"])
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_eval_only_two_ranks_equals_one_rank(tmp_path):
+    from test_data_pipeline import _make_voc
+    base = _make_voc(str(tmp_path))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    _eval_worker(0, 1, 0, base, ret)
+    mp.spawn(_eval_worker, args=(2, _free_port(), base, ret), nprocs=2, join=True)
+    one, two = ret["w1"], ret["w2"]
+    assert set(one) == set(two)
+    for k in one:
+        assert (one[k] != one[k] and two[k] != two[k]) or abs(one[k] - two[k]) < 1e-12, (k, one[k], two[k])
+    assert any(v == v and v > 0 for v in one.values()), one

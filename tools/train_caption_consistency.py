@@ -75,7 +75,7 @@ def main(args):
     if args.eval_only:              # train_caption_consistency.py:143-152: model.eval(); inference over the test sets
         from cddmsl_amd import evaluation
         assert args.voc_root, "--eval-only needs --voc-root (a VOC devkit year directory) : datasets are not shipped"
-        raise SystemExit(evaluation.run_eval_only(tr.model, cfg, args, rank))
+        raise SystemExit(evaluation.run_eval_only(tr.model, cfg, args, rank, world))
     if args.voc_root and args.dt_data:      # real paired data; default: seeded synthetic batches
         from cddmsl_amd import data
         from cddmsl_amd.evaluation import VOC_CLASS_NAMES
