@@ -86,6 +86,20 @@ def make_state_dict(seed=0, num_classes=20, layers=RN50_LAYERS, width=64, embed_
     return sd
 
 
+def drift_offline(sd: Dict[str, torch.Tensor], factor: float = 1.05) -> Dict[str, torch.Tensor]:
+    """The synthetic teacher (``offline_backbone.*``) starts as a copy of the student, which makes ``kd_loss`` exactly zero.
+    For checks that need a live KD term: scale the teacher's layer3 / layer4 conv weights by ``factor`` and its attention
+    pool's output projection by ``1 / factor`` (deterministic, in place; returns ``sd``)."""
+    for k, v in sd.items():
+        if not k.startswith("offline_backbone."):
+            continue
+        if (".layer3." in k or ".layer4." in k) and k.endswith(".weight") and v.dim() == 4:
+            v.mul_(factor)
+        elif k.endswith("attnpool.c_proj.weight"):
+            v.div_(factor)
+    return sd
+
+
 def make_state_dict_r50(seed=0, num_classes=20, num_anchors=15) -> Dict[str, torch.Tensor]:
     """Stock Detectron2 R50-C4 Faster R-CNN state dict (reference key names: ``backbone.stem.conv1.norm.weight``,
     ``backbone.res3.0.shortcut.weight``, ``roi_heads.res5.2.conv3.weight``, ``roi_heads.box_predictor.cls_score.bias``)."""

@@ -508,8 +508,9 @@ def gather_cat(x, others=None, rank=0):
     return torch.cat(parts, dim=0)
 
 
-def v2l_contrastive(sd, msd, cfg, img_src, img_tgt, kd, others=None, rank=0):
-    """GeneralizedRCNN.v2l_contrastive rcnn.py:255-319."""
+def v2l_contrastive(sd, msd, cfg, img_src, img_tgt, kd, others=None, rank=0, record=None):
+    """GeneralizedRCNN.v2l_contrastive rcnn.py:255-319.  ``others`` = (other ranks' target embeddings, other ranks' source
+    embeddings), each a list in rank order with this rank's slot skipped (``gather_cat``)."""
     ft = projector(sd, v2l(msd, cfg, attnpool(sd, cfg, backbone(sd, cfg, img_tgt)["res5"])))
     fs = v2l(msd, cfg, attnpool(sd, cfg, backbone(sd, cfg, img_src)["res5"]))
     kd_loss = None
@@ -519,6 +520,8 @@ def v2l_contrastive(sd, msd, cfg, img_src, img_tgt, kd, others=None, rank=0):
                                              p="offline_backbone.attnpool"))
         kd_loss = F.l1_loss(teacher.detach(), fs)
     fs = projector(sd, fs)
+    if record is not None:
+        record["img_emb_tgt"], record["img_emb_src"] = ft.detach(), fs.detach()
     o_t, o_s = (others or (None, None))
     ft = gather_cat(ft, o_t, rank)
     fs = gather_cat(fs, o_s, rank)
@@ -541,7 +544,7 @@ def forward(sd, cfg, batched_inputs, msd=None, branch="supervised", kd=True, gen
     if branch == "caption_consistency":  # rcnn.py:413-421
         src = preprocess_image_train(cfg, batched_inputs, "image")
         tgt = preprocess_image_train(cfg, batched_inputs, "image_trgt")
-        cont, kdl = v2l_contrastive(sd, msd, cfg, src, tgt, kd, others, rank)
+        cont, kdl = v2l_contrastive(sd, msd, cfg, src, tgt, kd, others, rank, record)
         return {"cont_loss": cont, "kd_loss": kdl} if kdl is not None else {"cont_loss": cont}
     if branch == "caption_consistency_regionLevel":  # rcnn.py:422-470
         src, sizes = preprocess_image(cfg, batched_inputs, "image")
@@ -561,6 +564,8 @@ def forward(sd, cfg, batched_inputs, msd=None, branch="supervised", kd=True, gen
         rt = attnpool(sd, cfg, layer4(sd, cfg, roi_pool(cfg, ft, boxes)))
         es = projector(sd, v2l(msd, cfg, rs))
         et = projector(sd, v2l(msd, cfg, rt))
+        if record is not None:
+            record["reg_emb_src"], record["reg_emb_tgt"] = es.detach(), et.detach()
         o_s, o_t = (others or (None, None))
         return symmetric_ce(gather_cat(es, o_s, rank), gather_cat(et, o_t, rank))
     # supervised: rcnn.py:592-623
@@ -579,15 +584,19 @@ def forward(sd, cfg, batched_inputs, msd=None, branch="supervised", kd=True, gen
     return losses
 
 
-def run_step_losses(sd, msd, cfg, batched_inputs, iteration, gen=None, record=None):
-    """SimpleTrainer.run_step engine/train_loop.py:311-383 up to ``losses = sum(...)``."""
+def run_step_losses(sd, msd, cfg, batched_inputs, iteration, gen=None, record=None, others=None, rank=0):
+    """SimpleTrainer.run_step engine/train_loop.py:311-383 up to ``losses = sum(...)``.  ``others`` (simulated world size > 1):
+    {"img": (other ranks' target embeddings, source embeddings), "reg": (source, target)} as ``record`` of those ranks' own
+    runs gives them (``img_emb_*``, ``reg_emb_*``); ``rank`` = this rank's slot in the gathered batch."""
     gen = gen if gen is not None else torch.Generator().manual_seed(0)
+    others = others or {}
     loss_dict = forward(sd, cfg, batched_inputs, branch="supervised", gen=gen, record=record)
     loss = {}
     if iteration > cfg.burn_in_iters:
-        loss.update(forward(sd, cfg, batched_inputs, msd, "caption_consistency", cfg.kd_regularization, gen))
+        loss.update(forward(sd, cfg, batched_inputs, msd, "caption_consistency", cfg.kd_regularization, gen, record=record,
+                            others=others.get("img"), rank=rank))
         loss["cont_region_loss"] = forward(sd, cfg, batched_inputs, msd, "caption_consistency_regionLevel",
-                                           cfg.kd_regularization, gen, record=record)
+                                           cfg.kd_regularization, gen, record=record, others=others.get("reg"), rank=rank)
     else:
         cc = forward(sd, cfg, batched_inputs, msd, "caption_consistency", False, gen)
         for k in cc:

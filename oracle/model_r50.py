@@ -5,8 +5,9 @@ Follows (paths under /root/reference/detectron2): modeling/backbone/resnet.py:10
 1x1), :330-359 (BasicStem), :362-459,614-695 (ResNet / build_resnet_backbone); modeling/roi_heads/roi_heads.py:358-512
 (Res5ROIHeads, mean pool); modeling/roi_heads/fast_rcnn.py:476-479,574-689 (plain linear classifier, CE, box L1);
 modeling/meta_arch/rcnn.py:592-623,758-768 (supervised forward, BGR mean/std without /255).
-Pinning: this architecture has no golden vectors from the reference's leaf modules yet ("parity unpinned" for the
-stock-ResNet wiring); its leaf ops (conv/FrozenBN/RPN/RoIAlign/matcher/losses) are the pinned ones of oracle/model.py.
+Pinning: backbone (stem, res2-4) and the RoI head's res5 stage + mean pool, with gradients, against the reference's own
+``backbone/resnet.py`` classes (tests/golden/ref_stock_resnet.npz, generator tests/golden/make_golden_step.py); RPN / RoIAlign /
+matcher / sampling / losses are the pinned functions of oracle/model.py.
 """
 import torch
 import torch.nn.functional as F

@@ -246,3 +246,148 @@ def test_oracle_inference_matches_reference():
     pb, ps, pc = om.detector_postprocess(b, s, c, (200, 300), 333, 480)
     assert torch.allclose(pb, torch.from_numpy(fx["post_boxes"]), rtol=0, atol=1e-4) and torch.equal(pc, torch.from_numpy(fx["post_classes"]))
     assert torch.equal(ps, torch.from_numpy(fx["post_scores"]))
+
+
+# ------------------------------------------------------------------------------------------------ step-level goldens
+# tests/golden/make_golden_step.py: the reference's OWN GeneralizedRCNN.forward (three branches, composed as SimpleTrainer.run_step
+# does), label_and_sample_proposals and clipping-SGD wrapper -- SURVEY.md 8(c) items (9), (10).
+STEP = dict(H=96, W=128, per_rank=2, roi_batch=16, pre=200, post=60, seed=77)
+
+
+def _step_cfg():
+    return om.Cfg(roi_batch_per_image=STEP["roi_batch"], rpn_pre_nms_topk=STEP["pre"], rpn_post_nms_topk=STEP["post"], kd_regularization=True)
+
+
+def _step_state():
+    sd = synthetic.drift_offline(synthetic.make_state_dict(0))
+    return sd, synthetic.make_mapper_state_dict(1)
+
+
+def _oracle_rank(rank, others=None, grad=True):
+    sd, msd = _step_state()
+    cfg = _step_cfg()
+    keys = om.trainable_keys(sd, cfg)
+    if grad:
+        for k in keys:
+            sd[k].requires_grad_(True)
+    batch = synthetic.make_batch(STEP["per_rank"], STEP["H"], STEP["W"], rank=rank, num_gt=3)
+    record = {}
+    with torch.set_grad_enabled(grad):
+        ld = om.run_step_losses(sd, msd, cfg, batch, 20000, torch.Generator().manual_seed(STEP["seed"] + rank), record=record,
+                                others=others, rank=rank)
+        if grad:
+            sum(ld.values()).backward()
+    return ld, sd, keys, record
+
+
+def _check_step(g, ld, sd, keys, record, loss_rtol=2e-4):
+    for k, v in ld.items():
+        want = float(g["loss/" + k])
+        assert abs(float(v) - want) <= loss_rtol * abs(want) + 1e-7, (k, float(v), want)
+    assert {k[5:] for k in g.files if k.startswith("loss/")} == set(ld)
+    # index stages, bit for bit: proposals kept by NMS, sampled RoI classes, the 16 region picks per image
+    for i in range(STEP["per_rank"]):
+        b, s = record["proposals"][i]
+        assert b.shape == g[f"prop_boxes{i}"].shape, (i, b.shape, g[f"prop_boxes{i}"].shape)
+        assert np.allclose(b.numpy(), g[f"prop_boxes{i}"], rtol=1e-5, atol=1e-3) and np.allclose(s.numpy(), g[f"prop_logits{i}"], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(record["roi_gt_classes"][i].numpy(), g[f"sampled_classes{i}"])
+        assert np.allclose(record["region_boxes"][i].numpy(), g[f"region_boxes{i}"], rtol=1e-5, atol=1e-3)
+    # gradients: every trainable tensor's norm and max, and slices of ten of them
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(keys) == names
+    for n, nrm, mx in zip(names, g["grad_norms"], g["grad_absmax"]):
+        gr = sd[n].grad
+        if mx < 1e-8:                                   # attnpool.k_proj.bias: exactly zero in exact arithmetic (softmax shift invariance)
+            assert float(gr.abs().max()) < 1e-7, n
+            continue
+        assert abs(float(gr.double().norm()) - nrm) <= 2e-3 * nrm + 1e-9, (n, float(gr.norm()), nrm)
+        assert abs(float(gr.abs().max()) - mx) <= 5e-3 * mx + 1e-9, (n, float(gr.abs().max()), mx)
+    sl = {"backbone.layer2.0.conv1.weight": np.s_[::4, ::8], "backbone.layer3.5.conv2.weight": np.s_[::16, ::16],
+          "backbone.layer4.0.downsample.0.weight": np.s_[::64, ::32], "backbone.attnpool.k_proj.weight": np.s_[::64, ::64],
+          "backbone.attnpool.positional_embedding": np.s_[:, ::64], "proposal_generator.rpn_head.conv.weight": np.s_[::64, ::64],
+          "proposal_generator.rpn_head.anchor_deltas.bias": np.s_[:], "roi_heads.box_predictor.bbox_pred.weight": np.s_[::4, ::32],
+          "projector.0.weight": np.s_[::24, ::24], "projector.2.bias": np.s_[:]}
+    for n, ix in sl.items():
+        want = g["grad/" + n]
+        got = sd[n].grad.numpy()[ix]
+        assert np.abs(got - want).max() <= 2e-3 * np.abs(want).max() + 1e-9, n
+
+
+def test_ref_run_step_world1():
+    """the oracle's run_step_losses == the reference's three forwards + backward (world size 1, KD on): 7 losses, the index
+    stages, all 48.4 M gradients (norms / maxima of every tensor + slices)"""
+    g = _npz("ref_step_w1_r0.npz")
+    assert list(g["meta"][:3]) == [1, 0, 1]
+    ld, sd, keys, record = _oracle_rank(0)
+    assert float(ld["kd_loss"]) > 1e-3
+    _check_step(g, ld, sd, keys, record)
+
+
+@pytest.mark.parametrize("rank", [0, 1])
+def test_ref_run_step_world2(rank):
+    """world size 2 (two real gloo ranks in the generator): the cross-rank contrastive batch (GatherLayer forward = all ranks'
+    embeddings, backward = own slice) against the oracle's simulated ranks -- the other rank's embeddings come from the oracle's
+    own no-grad run of that rank's batch."""
+    g = _npz(f"ref_step_w2_r{rank}.npz")
+    assert list(g["meta"][:3]) == [2, rank, 1]
+    _, _, _, rec_o = _oracle_rank(1 - rank, grad=False)
+    others = {"img": ([rec_o["img_emb_tgt"]], [rec_o["img_emb_src"]]), "reg": ([rec_o["reg_emb_src"]], [rec_o["reg_emb_tgt"]])}
+    ld, sd, keys, record = _oracle_rank(rank, others=others)
+    _check_step(g, ld, sd, keys, record)
+    # both ranks see the same full-matrix loss
+    g_other = _npz(f"ref_step_w2_r{1 - rank}.npz")
+    assert abs(float(g["loss/cont_loss"]) - float(g_other["loss/cont_loss"])) < 1e-6
+
+
+def test_ref_roi_sampling():
+    """oracle label_and_sample_proposals vs the reference's ROIHeads.label_and_sample_proposals (roi_heads.py:236-319): sampled
+    boxes, logits, classes and matched GT boxes per image, incl. an image without ground truth and one with few candidates"""
+    g = _npz("ref_roi_sampling.npz")
+    cfg = om.Cfg(roi_batch_per_image=64)
+    props = [(T(g[f"boxes{i}"]), T(g[f"logits{i}"])) for i in range(3)]
+    gtb = [T(g[f"gt_boxes{i}"]).reshape(-1, 4) for i in range(3)]
+    gtc = [T(g[f"gt_classes{i}"]).long() for i in range(3)]
+    out = om.label_and_sample_proposals(cfg, props, gtb, gtc, torch.Generator().manual_seed(92))
+    nfg = nbg = 0
+    for i, o in enumerate(out):
+        assert np.array_equal(o["proposal_boxes"].numpy(), g[f"s_boxes{i}"]) and np.array_equal(o["gt_classes"].numpy(), g[f"s_classes{i}"])
+        assert np.allclose(o["objectness_logits"].numpy(), g[f"s_logits{i}"])
+        assert ("gt_boxes" in o) == (f"s_gt_boxes{i}" in g.files)
+        if "gt_boxes" in o:
+            assert np.array_equal(o["gt_boxes"].numpy(), g[f"s_gt_boxes{i}"])
+        nfg += int((o["gt_classes"] != 20).sum())
+        nbg += int((o["gt_classes"] == 20).sum())
+    assert np.allclose([nfg / 3, nbg / 3], g["num_fg_bg"])
+
+
+def test_ref_sgd():
+    """oracle sgd_step vs the reference's clipping-SGD class (solver/build.py:43-110 around torch.optim.SGD): three steps"""
+    g = _npz("ref_sgd.npz")
+    names = ["a.weight", "b.weight", "b.bias", "c.weight"]
+    sd = {k: T(g["w0/" + k]) for k in names}
+    mom = {}
+    for step, lr in enumerate(g["lrs"]):
+        cfg = om.Cfg(base_lr=float(lr), warmup_iters=0, steps=(), clip_value=5.0)
+        assert abs(om.sgd_step(sd, {k: T(g[f"g{step}/" + k]) for k in names}, mom, cfg, 10) - float(lr)) < 1e-12
+        for k in names:
+            assert np.allclose(sd[k].numpy(), g[f"w{step + 1}/" + k], rtol=1e-6, atol=1e-7), (step, k)
+
+
+def test_ref_stock_resnet():
+    """oracle/model_r50.py (config #1) vs the reference's own stock ResNet (backbone/resnet.py) and res5 stage: res4 on a seeded
+    image, the RoI head's res5 + mean pool with input / weight gradients"""
+    from oracle import model_r50 as r50
+    g = _npz("ref_stock_resnet.npz")
+    sd = synthetic.make_state_dict_r50(0)
+    with torch.no_grad():
+        res4 = r50.backbone(sd, seeded((2, 3, 64, 96), 111, 50.0))
+    assert np.allclose(res4.numpy(), g["res4"], rtol=1e-4, atol=1e-5)
+    for k in ("roi_heads.res5.0.conv1.weight", "roi_heads.res5.2.conv2.weight"):
+        sd[k] = sd[k].clone().requires_grad_(True)
+    x = seeded((3, 1024, 14, 14), 112).requires_grad_(True)
+    feats = r50.stage(sd, "roi_heads.res5", x, 3, 2).mean(dim=[2, 3])
+    assert np.allclose(feats.detach().numpy(), g["res5_mean"], rtol=1e-4, atol=1e-5)
+    (feats * seeded(tuple(feats.shape), 113)).sum().backward()
+    assert np.allclose(x.grad[:, ::16].numpy(), g["gx"], rtol=1e-3, atol=1e-7)
+    assert np.allclose(sd["roi_heads.res5.0.conv1.weight"].grad[::8, ::16, 0, 0].numpy(), g["gw"], rtol=1e-3, atol=1e-6)
+    assert np.allclose(sd["roi_heads.res5.2.conv2.weight"].grad[::16, ::16].numpy(), g["gw3"], rtol=1e-3, atol=1e-6)
