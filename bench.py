@@ -201,7 +201,7 @@ def main():
     # RN50-C4 supervised FORWARD alone (backbone to res4, RPN, RoIAlign, RoI layer4, attention pool, classifier, losses), the
     # quantity BASELINE.json's roofline target is stated on: algorithmic 1.878 TFLOP per 800x1333 image (SURVEY.md 8(d):
     # 938.8 GMAC, query-0-only attention pool), timed outside the step timing above, rank 0's own clock
-    fwd_ms = None
+    fwd_ms = fwd_kernels = fwd_shapes = None
     if world == 1 and (args.height, args.width) == (800, 1333) and not args.no_forward_roofline:
         data = next(tr._data_loader_iter)
         tr.model.share_source_pass = False
@@ -213,6 +213,10 @@ def main():
             tr.model(data)
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - tf0) / 5 * 1e3
+        hip.PROFILE.enable()                            # one more, fully instrumented: the forward-only per-kernel table
+        tr.model(data)
+        fwd_shapes = hip.PROFILE.by_shape()
+        fwd_kernels = hip.PROFILE.collect()
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -264,7 +268,9 @@ def main():
             ftf = 1.878 * args.batch
             out["forward_roofline"] = {"what": "supervised RN50-C4 forward only (autograd recording on), algorithmic 1.878 TFLOP/image",
                                        "ms": fwd_ms, "achieved": ftf / (fwd_ms * 1e-3), "peak": peak, "unit": "TFLOP/s",
-                                       "frac": ftf / (fwd_ms * 1e-3) / peak, "images_per_sec_forward": args.batch / (fwd_ms * 1e-3)}
+                                       "frac": ftf / (fwd_ms * 1e-3) / peak, "images_per_sec_forward": args.batch / (fwd_ms * 1e-3),
+                                       "kernels_ms": {k: round(v["ms"], 3) for k, v in fwd_kernels.items()},
+                                       "kernels_ms_note": "one instrumented forward (event pairs on every launch); the ms above is un-instrumented"}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
             out["cpu_baseline"] = cpu_baseline(args.height, args.width, threads, timed=max(args.cpu_baseline_steps, 1))

@@ -412,7 +412,7 @@ def _city_cfg(dtype, **over):
 def _build_city(cfg, seed):
     from cddmsl_amd import synthetic
     from cddmsl_amd.modeling import build_model, TransformerMapper
-    sd = synthetic.make_state_dict(0, num_classes=8)
+    sd = synthetic.drift_offline(synthetic.make_state_dict(0, num_classes=8))      # teacher != student: a live kd_loss
     msd = synthetic.make_mapper_state_dict(1)
     model = build_model(cfg)
     missing, unexpected = model.load_state_dict(sd, strict=False)
@@ -499,10 +499,13 @@ def test_adverse_weather_full_size_bf16_step():
 
 # Teacher-forced bf16 bound.  What bf16 can and cannot hold: the backbone + RoI head run ~50 bf16 GEMM layers (8 significant
 # bits per operand, f32 accumulation), the classifier multiplies cosine similarities by 1/T = 100 and every loss is f32.
-# Measured on MI355X (this test prints the numbers): losses differ from the exact-f32 HIP path by <= ~1 %, gradient tensors by
-# <= ~3 % of their max.  The asserted bounds carry a 2x margin over the worst value seen.
-BF16_LOSS_REL = 3e-2
+# Measured on MI355X (this test prints the numbers; identical for both kernel dispatches, the 256x256 kernels being bit-equal to
+# the 128x128 ones): worst loss 0.33 % off the exact-f32 HIP path; gradient tensors <= 3.8 % of their max (cosine >= 0.9996)
+# except the projector (projector.0.* 19 %, cosine 0.991; projector.2.weight 5.7 %).  The asserted bounds carry ~2x margin.
+BF16_LOSS_REL = 1.5e-2
 BF16_GRAD_REL = 8e-2
+BF16_GRAD_REL_HEAD = 3e-1     # projector.*: gradients of the un-tempered contrastive losses on near-identical source / target embeddings
+BF16_GRAD_COS = 0.97          # (S ~ all ones: the gradient is a small difference of large terms) -- direction still has to agree
 
 
 @pytest.mark.parametrize("gemm256", ["1", "2"])
@@ -519,17 +522,25 @@ def test_bf16_step_is_close_to_f32_step_with_forced_indices(gemm256, monkeypatch
     bf_losses, bf_grads, rec_bf, _ = _hip_step(_cfg("bf16", kd=True), batch, seed=5, replay=rec)
     assert set(bf_losses) == set(f32_losses) and set(bf_grads) == set(f32_grads)
     worst_l = max(abs(bf_losses[k] - f32_losses[k]) / max(abs(f32_losses[k]), 1e-6) for k in f32_losses)
-    worst_g, worst_k = 0.0, None
+    errs = []
     for k, r in f32_grads.items():
-        e = float((bf_grads[k] - r).abs().max() / max(float(r.abs().max()), 1e-5))
-        if e > worst_g:
-            worst_g, worst_k = e, k
+        if float(r.abs().max()) < 1e-7:               # attnpool.k_proj.bias: exactly zero in exact arithmetic
+            continue
+        e = float((bf_grads[k] - r).abs().max() / float(r.abs().max()))
+        cos = float(torch.nn.functional.cosine_similarity(bf_grads[k].flatten().double(), r.flatten().double(), dim=0))
+        errs.append((e, cos, k))
+    errs.sort(reverse=True)
+    worst_g, _, worst_k = errs[0]
+    worst_cos = min(e[1] for e in errs)
     own = _proposal_diff(rec_bf[0], rec[0])
-    print(f"bf16 vs f32 (forced indices, gemm256={gemm256}): worst loss rel {worst_l:.4f}, worst grad rel {worst_g:.4f} ({worst_k}); "
-          f"bf16's own proposal list differs from f32's in {own} of {sum(len(b) for b, _ in rec[0])} entries")
+    print(f"bf16 vs f32 (forced indices, gemm256={gemm256}): worst loss rel {worst_l:.4f}, worst grad rel {worst_g:.4f} ({worst_k}), "
+          f"worst cosine {worst_cos:.5f}; bf16's own proposal list differs from f32's in {own} of {sum(len(b) for b, _ in rec[0])} entries")
+    print("  largest gradient deviations (max-abs / tensor max, cosine, tensor):", [(round(e, 4), round(c, 5), k) for e, c, k in errs[:10]])
     for k in f32_losses:
         assert abs(bf_losses[k] - f32_losses[k]) <= BF16_LOSS_REL * abs(f32_losses[k]) + 1e-5, (k, bf_losses[k], f32_losses[k])
-    assert worst_g <= BF16_GRAD_REL, (worst_k, worst_g)
+    for e, cos, k in errs:
+        assert e <= (BF16_GRAD_REL_HEAD if k.startswith("projector.") else BF16_GRAD_REL), (k, e, cos)
+        assert cos >= BF16_GRAD_COS, (k, e, cos)
 
 
 def test_load_state_dict_after_a_forward_takes_effect():
