@@ -82,9 +82,13 @@ constexpr int ROI_MAXS = 256;     // samples per axis held in LDS (adaptive samp
 // RoI head's layer4 pools its input for the downsample path (clip_backbone.py:45-52), and reading the 3.3 GB map back just
 // for that costs more than computing four neighbouring bins in one thread.  The pooled value is formed from the four ROUNDED
 // outputs in avgpool2_fwd's order, so it is bit-identical to pooling the stored map.
+// ``y`` may be absent (RP = 2: only the pooled map is wanted); ``esc`` / ``ebi`` (per channel) and ``relu``: y = relu?(esc * v + ebi)
+// applied to the pooled-over-samples value before it is rounded -- the FrozenBN + ReLU of a 1x1 convolution that was applied to
+// the feature map BEFORE the pooling (both are linear: see cddmsl_roi_align_forward_affine).
 template <typename T, int RP>
 __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char* yp, int* dbg_grid, int N, int H, int W, int cch,
-                                int ph, int pw, float scale, int sampling_ratio, int aligned) {
+                                int ph, int pw, float scale, int sampling_ratio, int aligned, const float* esc, const float* ebi,
+                                int relu) {
   const int nrb = ph / RP;
   const int i0 = (blockIdx.x % nrb) * RP, k = blockIdx.x / nrb;
   RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
@@ -179,8 +183,16 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char*
 #pragma unroll
       for (int q = 0; q < VEC; ++q) acc[q] /= count;
     }
+    if (esc) {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        const float sq = esc[c * VEC + q], bq = ebi[c * VEC + q];
+        acc[q] = sizeof(T) == 2 ? __builtin_fmaf(acc[q], sq, bq) : acc[q] * sq + bq;       // (as the conv epilogues: gemm_conv.hip affine<T>)
+        if (relu) acc[q] = fmaxf(acc[q], 0.f);
+      }
+    }
     outp[rr][cc] = Vec<T>::pack(acc);
-    ((u32x4*)y)[bin * cch + c] = outp[rr][cc];
+    if (y) ((u32x4*)y)[bin * cch + c] = outp[rr][cc];
     }
     if (RP == 2) {
       float a0[8], a1[8], a2[8], a3[8], o[8];
@@ -197,10 +209,13 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char*
 // Per-RoI separable weight tables: ay[k][py][bi] = (1/gh) sum_{iy in bin bi} wy(py; y_iy), likewise ax (1/gw).
 // (count = max(gh*gw,1) = gh*gw whenever any sample exists.)  Also the footprint box fp[k] = (ylo,yhi,xlo,xhi)
 // inclusive, empty when ylo > yhi.
+// ``fold`` = 2: the gradient arrives on the 2x2-AVERAGE-POOLED map (ph x pw there; the RoIAlign grid is 2 ph x 2 pw): pooling is
+// separable as well (0.5 per axis), so table column i collects the two bins 2i, 2i+1 at half weight and the same gather kernel
+// walks ph x pw pooled bins -- it reads a quarter of the gradient bytes and never sees the full-resolution tensor.
 __global__ void k_roi_tables(const float* rois, float* ay, float* ax, int* fp, int K, int H, int W, int ph, int pw,
-                             float scale, int sampling_ratio, int aligned) {
+                             float scale, int sampling_ratio, int aligned, int fold) {
   int k = blockIdx.x;
-  RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
+  RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph * fold, pw * fold, sampling_ratio, aligned);
   float* ayk = ay + (long)k * H * ph;
   float* axk = ax + (long)k * W * pw;
   for (int i = threadIdx.x; i < H * ph; i += blockDim.x) ayk[i] = 0.f;
@@ -208,26 +223,30 @@ __global__ void k_roi_tables(const float* rois, float* ay, float* ax, int* fp, i
   __shared__ int lim[4];
   if (threadIdx.x == 0) { lim[0] = H; lim[1] = -1; lim[2] = W; lim[3] = -1; }
   __syncthreads();
-  // one thread per bin per axis; bins of an axis write disjoint table columns
+  const float fw = 1.0f / (float)fold;
+  // one thread per table column per axis (fold bins each); columns of an axis are disjoint
   if (threadIdx.x < ph) {
-    int i = threadIdx.x, lo_min = H, hi_max = -1;
+    int lo_min = H, hi_max = -1;
+    for (int i = threadIdx.x * fold; i < (threadIdx.x + 1) * fold; ++i)
     for (int iy = 0; iy < g.gh; ++iy) {
       float yy = g.y0 + (float)i * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
       int yl, yh; float wl, wh;
       if (!axis_tap(yy, H, yl, yh, wl, wh)) continue;
-      ayk[yl * ph + i] += wl / (float)g.gh;
-      ayk[yh * ph + i] += wh / (float)g.gh;
+      ayk[yl * ph + threadIdx.x] += fw * (wl / (float)g.gh);
+      ayk[yh * ph + threadIdx.x] += fw * (wh / (float)g.gh);
       lo_min = min(lo_min, yl); hi_max = max(hi_max, yh);
     }
     atomicMin(&lim[0], lo_min); atomicMax(&lim[1], hi_max);
   } else if (threadIdx.x >= 64 && threadIdx.x < 64 + pw) {
-    int j = threadIdx.x - 64, lo_min = W, hi_max = -1;
+    const int jc = threadIdx.x - 64;
+    int lo_min = W, hi_max = -1;
+    for (int j = jc * fold; j < (jc + 1) * fold; ++j)
     for (int ix = 0; ix < g.gw; ++ix) {
       float xx = g.x0 + (float)j * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
       int xl, xh; float wl, wh;
       if (!axis_tap(xx, W, xl, xh, wl, wh)) continue;
-      axk[xl * pw + j] += wl / (float)g.gw;
-      axk[xh * pw + j] += wh / (float)g.gw;
+      axk[xl * pw + jc] += fw * (wl / (float)g.gw);
+      axk[xh * pw + jc] += fw * (wh / (float)g.gw);
       lo_min = min(lo_min, xl); hi_max = max(hi_max, xh);
     }
     atomicMin(&lim[2], lo_min); atomicMax(&lim[3], hi_max);
@@ -333,30 +352,50 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(const char* dy, const flo
 
 }  // namespace
 
-extern "C" int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, void* y_pooled, int* dbg_grid, int N, int C,
-                                        int H, int W, int K, int ph, int pw, float spatial_scale, int sampling_ratio,
-                                        int aligned, int dtype, void* stream) {
+static int roi_align_forward_impl(const void* x, const float* rois, void* y, void* y_pooled, int* dbg_grid, const float* esc,
+                                  const float* ebi, int relu, int N, int C, int H, int W, int K, int ph, int pw, float spatial_scale,
+                                  int sampling_ratio, int aligned, int dtype, void* stream) {
   int es = dtype == 0 ? 2 : 4;
   if ((dtype != 0 && dtype != 1) || (C * es) % 16 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || K < 0 || N < 0)
     return CDDMSL_ERR_ARG;
+  if ((esc == nullptr) != (ebi == nullptr)) return CDDMSL_ERR_ARG;
   if (K == 0) return CDDMSL_OK;   // empty inputs return correctly-shaped empties (poolers.py:221-224)
+  if (!y && !y_pooled) return CDDMSL_ERR_ARG;
   int cch = C * es / 16;
   if (y_pooled && ((ph & 1) || (pw & 1))) return CDDMSL_ERR_ARG;      // the pooled copy needs whole 2x2 groups of bins
   long grid = (long)K * (y_pooled ? ph / 2 : ph);
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   int threads = cch >= 256 ? 256 : ((cch + 63) / 64) * 64;
   hipStream_t st = (hipStream_t)stream;
-#define CDDMSL_RAF(TT, RPP) k_roi_align_fwd<TT, RPP><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, (char*)y_pooled, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned)
+#define CDDMSL_RAF(TT, RPP) k_roi_align_fwd<TT, RPP><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, (char*)y_pooled, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned, esc, ebi, relu)
   if (dtype == 0) { if (y_pooled) CDDMSL_RAF(__bf16, 2); else CDDMSL_RAF(__bf16, 1); }
   else { if (y_pooled) CDDMSL_RAF(float, 2); else CDDMSL_RAF(float, 1); }
 #undef CDDMSL_RAF
   return launch_status();
 }
 
-// ws_ay: K*H*ph floats, ws_ax: K*W*pw floats, ws_fp: 4*K ints; roi_start: N+1 ints (device)
-extern "C" int cddmsl_roi_align_backward(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,
-                                         float* ws_ax, int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw,
-                                         float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream) {
+extern "C" int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, void* y_pooled, int* dbg_grid, int N, int C,
+                                        int H, int W, int K, int ph, int pw, float spatial_scale, int sampling_ratio,
+                                        int aligned, int dtype, void* stream) {
+  if (!y && K > 0) return CDDMSL_ERR_ARG;
+  return roi_align_forward_impl(x, rois, y, y_pooled, dbg_grid, nullptr, nullptr, 0, N, C, H, W, K, ph, pw, spatial_scale,
+                                sampling_ratio, aligned, dtype, stream);
+}
+
+// RoIAlign of a map that already went through a 1x1 convolution: y = relu?(scale[c] * roi_align(x)[..., c] + bias[c]), and / or
+// (y NULL allowed) only the 2x2-average-pooled map y_pooled.  Used by the RoI head's first bottleneck, whose conv1 and
+// downsample AvgPool2d are moved across the pooling (cddmsl_amd/layers.py RoIStageFn): RoIAlign is linear over pixels, a 1x1
+// convolution over channels, so roi_align(x) W = roi_align(x W); the FrozenBN affine and the ReLU follow here.
+extern "C" int cddmsl_roi_align_forward_affine(const void* x, const float* rois, void* y, void* y_pooled, const float* scale,
+                                               const float* bias, int relu, int N, int C, int H, int W, int K, int ph, int pw,
+                                               float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream) {
+  return roi_align_forward_impl(x, rois, y, y_pooled, nullptr, scale, bias, relu, N, C, H, W, K, ph, pw, spatial_scale,
+                                sampling_ratio, aligned, dtype, stream);
+}
+
+static int roi_align_backward_impl(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,
+                                   float* ws_ax, int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw,
+                                   float spatial_scale, int sampling_ratio, int aligned, int dtype, int fold, void* stream) {
   int es = dtype == 0 ? 2 : 4;
   if ((dtype != 0 && dtype != 1) || (C * es) % 16 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || K < 0 || N < 0)
     return CDDMSL_ERR_ARG;
@@ -365,7 +404,7 @@ extern "C" int cddmsl_roi_align_backward(const void* dy, const float* rois, cons
   if (cch > 1024) return CDDMSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) return CDDMSL_OK;
-  if (K > 0) k_roi_tables<<<dim3((unsigned)K), dim3(128), 0, st>>>(rois, ws_ay, ws_ax, ws_fp, K, H, W, ph, pw, spatial_scale, sampling_ratio, aligned);
+  if (K > 0) k_roi_tables<<<dim3((unsigned)K), dim3(128), 0, st>>>(rois, ws_ay, ws_ax, ws_fp, K, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, fold);
   int threads = cch >= 256 ? 256 : ((cch + 63) / 64) * 64;
   const int ncpt = (cch + threads - 1) / threads;
   const int ts = 2;                                 // 2x2 tiles (4x4 tiles measured slower both before (6.7 vs 3.0 ms) and after the ballot rewrite (2.75 vs 1.36 ms))
@@ -376,4 +415,21 @@ extern "C" int cddmsl_roi_align_backward(const void* dy, const float* rois, cons
   else { if (ncpt <= 1) CDDMSL_RAB(float, 1, 2); else if (ncpt == 2) CDDMSL_RAB(float, 2, 2); else CDDMSL_RAB(float, 4, 2); }
 #undef CDDMSL_RAB
   return launch_status();
+}
+
+// ws_ay: K*H*ph floats, ws_ax: K*W*pw floats, ws_fp: 4*K ints; roi_start: N+1 ints (device)
+extern "C" int cddmsl_roi_align_backward(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,
+                                         float* ws_ax, int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw,
+                                         float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream) {
+  return roi_align_backward_impl(dy, rois, roi_start, dx, ws_ay, ws_ax, ws_fp, N, C, H, W, K, ph, pw, spatial_scale,
+                                 sampling_ratio, aligned, dtype, 1, stream);
+}
+
+// Backward of avgpool2(roi_align(x)): dy is the gradient of the POOLED map [K][ph][pw][C] (RoIAlign grid 2 ph x 2 pw);
+// equal to cddmsl_roi_align_backward applied to the AvgPool2d(2) backward of dy, without forming that tensor.
+extern "C" int cddmsl_roi_align_backward_pooled(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,
+                                                float* ws_ax, int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw,
+                                                float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream) {
+  return roi_align_backward_impl(dy, rois, roi_start, dx, ws_ay, ws_ax, ws_fp, N, C, H, W, K, ph, pw, spatial_scale,
+                                 sampling_ratio, aligned, dtype, 2, stream);
 }

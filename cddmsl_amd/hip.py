@@ -45,6 +45,8 @@ def _L():
         L.cddmsl_sgd_clip_step.argtypes = [vp] * 4 + [ci, vp] + [cf] * 4 + [ci, vp]
         L.cddmsl_roi_align_forward.argtypes = [vp] * 5 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_roi_align_backward.argtypes = [vp] * 7 + [ci] * 7 + [cf, ci, ci, ci, vp]
+        L.cddmsl_roi_align_forward_affine.argtypes = [vp] * 6 + [ci] * 8 + [cf, ci, ci, ci, vp]
+        L.cddmsl_roi_align_backward_pooled.argtypes = [vp] * 7 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_anchors.argtypes = [vp, vp, ci, ci, ci, cf, cf, vp]
         L.cddmsl_sort_desc.argtypes = [vp] * 5 + [ci, ci, vp, vp, vp]
         L.cddmsl_rpn_decode.argtypes = [vp] * 6 + [ci] * 5 + [cf] * 8 + [vp]
@@ -469,9 +471,32 @@ def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, d
     return (y, yp) if with_pooled else y
 
 
+@_timed("roi_align_forward")
+def roi_align_forward_affine(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, scale=None, bias=None, relu=False,
+                             pooled_only=False, extra_rows=0):
+    """RoIAlign of a map that already went through a 1x1 convolution (layers.RoIStageFn):
+    ``pooled_only=False``: y [K,ph,pw,C] = relu?(scale * roi_align(x) + bias) (per channel, f32 scale / bias);
+    ``pooled_only=True``: only AvgPool2d(2) of the crops, [K,ph/2,pw/2,C] (no affine) -- the full-resolution crops are never written."""
+    require_cuda(x, rois)
+    assert rois.dim() == 2 and rois.size(1) == 5 and rois.dtype == torch.float32 and rois.is_contiguous()
+    assert (scale is None) == (bias is None) and not (pooled_only and scale is not None)
+    N, H, W, C = x.shape
+    K = rois.shape[0]
+    if pooled_only:
+        y, yp = None, torch.empty((K + extra_rows, ph // 2, pw // 2, C), device=x.device, dtype=x.dtype)
+    else:
+        y, yp = torch.empty((K + extra_rows, ph, pw, C), device=x.device, dtype=x.dtype), None
+        assert scale is None or (scale.dtype == torch.float32 and scale.numel() == C and bias.numel() == C and scale.is_contiguous() and bias.is_contiguous())
+    check(_L().cddmsl_roi_align_forward_affine(ptr(x), ptr(rois), ptr(y), ptr(yp), ptr(scale), ptr(bias), int(relu), N, C, H, W, K,
+                                                ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(x), stream_ptr()),
+          "cddmsl_roi_align_forward_affine")
+    return yp if pooled_only else y
+
+
 @_timed("roi_align_backward")
-def roi_align_backward(dy, rois, roi_start, in_shape, spatial_scale, sampling_ratio, aligned):
-    """dy [K,ph,pw,C] -> dx NHWC in_shape.  rois must be grouped by image; roi_start int32 [N+1] prefix offsets."""
+def roi_align_backward(dy, rois, roi_start, in_shape, spatial_scale, sampling_ratio, aligned, pooled=False):
+    """dy [K,ph,pw,C] -> dx NHWC in_shape.  rois must be grouped by image; roi_start int32 [N+1] prefix offsets.
+    ``pooled``: dy is the gradient of AvgPool2d(2) of the crops (the RoIAlign grid is 2ph x 2pw)."""
     require_cuda(dy, rois, roi_start)
     N, H, W, C = in_shape
     K, ph, pw, _ = dy.shape
@@ -480,9 +505,9 @@ def roi_align_backward(dy, rois, roi_start, in_shape, spatial_scale, sampling_ra
     ay = workspace("roi_ay", max(K, 1) * H * ph * 4, dy.device)
     ax = workspace("roi_ax", max(K, 1) * W * pw * 4, dy.device)
     fp = workspace("roi_fp", max(K, 1) * 16, dy.device)
-    check(_L().cddmsl_roi_align_backward(ptr(dy), ptr(rois), ptr(roi_start), ptr(dx), ptr(ay), ptr(ax), ptr(fp), N, C, H, W, K,
-                                          ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(dy), stream_ptr()),
-          "cddmsl_roi_align_backward")
+    fn = _L().cddmsl_roi_align_backward_pooled if pooled else _L().cddmsl_roi_align_backward
+    check(fn(ptr(dy), ptr(rois), ptr(roi_start), ptr(dx), ptr(ay), ptr(ax), ptr(fp), N, C, H, W, K,
+             ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(dy), stream_ptr()), "cddmsl_roi_align_backward")
     return dx
 
 

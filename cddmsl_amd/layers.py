@@ -87,7 +87,7 @@ class PreparedWeight:
     def _refresh_all(dtype):
         """one launch for every trainable weight that has buffers of this dtype and was used last step"""
         items = [pw for pw in PreparedWeight._live if pw._wf is not None and pw._dtype == dtype and pw._used
-                 and pw._key is not None and pw._key[2:] == (pw.param.data_ptr(), pw.param._version)]
+                 and pw._key is not None and pw._key[2] == pw.param.data_ptr()]   # (same storage; the refresh re-reads the master whatever its version)
         if not items:
             return
         sig = tuple(pw._sig() for pw in items)
@@ -387,6 +387,124 @@ def res_stage_attnpool(x, blocks, frozen, ap):
     over the [K,7,7,2048] tensor.  Only valid because nothing else consumes the stage output -- which this function owns."""
     fuse = not frozen and torch.is_grad_enabled()
     y = res_stage(x, blocks, frozen, out_grad_premasked=fuse)
+    return AttnPoolFn.apply(y, None if ap.frozen else ap.q_w, ap, fuse)
+
+
+# ------------------------------------------------------------------------------------------------
+# RoIAlign -> CLIP layer4 with the first block's conv1 moved in front of the pooling
+# ------------------------------------------------------------------------------------------------
+def _roi_block0_forward(feat, rois, bp, out_size, scale, sr, extra):
+    """First Bottleneck of the RoI head's layer4 (clip_roi_heads.py:113-115 -> clip_backbone.py:57-70) on the pooled crops, WITHOUT
+    the crops: RoIAlign is a linear map over pixels and conv1 / the downsample conv are 1x1 (linear over channels), so
+
+        relu(bn1(conv1(roi_align(x))))    = relu(s1 * roi_align(conv1(x)) + b1)          (conv1 runs once per image pixel: 66 400
+        avgpool2(roi_align(x))  (-> downsample conv)  written directly, pooled           rows instead of 1.6 M crop rows at 8192 RoIs)
+
+    The [K,14,14,1024] crop tensor (3.3 GB) is never written or read; the 512-channel o1 (half of it) is what conv2 needs
+    anyway.  Returns (o1, o2, p2, px, out)."""
+    T = feat.dtype
+    (s1, b1), (s2, b2), (s3, b3), bnd = bp.bn
+    w1, _ = bp.pw[0].get(T, False)
+    w2, _ = bp.pw[1].get(T, False)
+    w3, _ = bp.pw[2].get(T, False)
+    wd, _ = bp.pw[3].get(T, False)
+    K, E = rois.shape[0], (0 if extra is None else extra.shape[0])
+    z = hip.conv_fwd(feat, w1)                                                              # conv1 on the feature map, no affine yet
+    o1 = hip.roi_align_forward_affine(z, rois, out_size, out_size, scale, sr, True, s1, b1, relu=True, extra_rows=E)
+    px = hip.roi_align_forward_affine(feat, rois, out_size, out_size, scale, sr, True, pooled_only=True, extra_rows=E)
+    if E:                                            # maps of the crops' geometry riding behind them (the 224x224 crops' res4)
+        o1[K:].copy_(hip.conv_fwd(extra, w1, s1, b1, relu=True))
+        px[K:].copy_(hip.avgpool2_fwd(extra))
+    o2 = hip.conv_fwd(o1, w2, s2, b2, relu=True, pad=1)
+    p2 = hip.avgpool2_fwd(o2)
+    idn = hip.conv_fwd(px, wd, bnd[0], bnd[1])
+    out = hip.conv_fwd(p2, w3, s3, b3, residual=idn, relu=True)
+    return o1, o2, p2, px, out
+
+
+class RoIStageFn(torch.autograd.Function):
+    """pooler (poolers.py:190-229) + ``backbone.layer4`` (clip_roi_heads.py:113-115) as ONE autograd node, first block as in
+    ``_roi_block0_forward``.  Backward of that block: the gradient of o1 goes back through the RoIAlign gather at 512 channels
+    to the feature-map-level conv1 (its weight gradient is a 66 400-row reduction, its input gradient a 66 400-row GEMM), the
+    downsample path's gradient through the gather on the POOLED 7x7 grid (a quarter of the bytes)."""
+
+    @staticmethod
+    def forward(ctx, feat, anchor, rois, roi_start, blocks, out_size, scale, sr, out_grad_premasked, extra):
+        feat = feat.contiguous()
+        o1, o2, p2, px, cur = _roi_block0_forward(feat, rois, blocks[0], out_size, scale, sr, extra)
+        saved = [feat, rois, roi_start, extra, o1, o2, p2, px, cur]
+        for bp in blocks[1:]:
+            cur, mids = _block_forward(cur, bp, True)
+            saved += [mids[0], mids[1], mids[2], mids[3], cur]
+        ctx.blocks, ctx.meta = blocks, (out_size, scale, sr, out_grad_premasked)
+        ctx.save_for_backward(*saved)
+        return cur
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        blocks = ctx.blocks
+        out_size, scale, sr, premasked = ctx.meta
+        feat, rois, roi_start, extra = saved[:4]
+        st = saved[4:]                               # per block: o1, o2, p2, px, out
+        gs = g.contiguous() if premasked else hip.relu_bwd(g.contiguous(), st[-1])
+        for i in range(len(blocks) - 1, 0, -1):
+            o1, o2, p2, px = st[5 * i: 5 * i + 4]
+            gs = _block_backward(gs, st[5 * i - 1], o1, o2, p2, px, blocks[i], True, mask_x=True)
+        bp = blocks[0]
+        o1, o2, p2, px = st[0:4]
+        T = o1.dtype
+        (s1, _), (s2, _), (s3, _), bnd = bp.bn
+        w1p, w2p, w3p, wdp = bp.w
+        shp = lambda w: _ohwi(w).shape
+        K, E = rois.shape[0], (0 if extra is None else extra.shape[0])
+        hip.conv_wgrad(p2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
+        _, w3d = bp.pw[2].get(T, True)
+        dpre2 = hip.avgpool2_bwd(hip.conv_fwd(gs, w3d), tuple(o2.shape), mask=o2)
+        hip.conv_wgrad(o1, dpre2, shp(w2p), s2, pad=1, out=_ohwi(_grad_buf(w2p)))
+        _, w2d = bp.pw[1].get(T, True)
+        dpre1 = hip.conv_fwd(dpre2, w2d, pad=1, relu_mask=o1)                               # [K+E,14,14,planes] wrt bn1's output
+        hip.conv_wgrad(px, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
+        _, wdd = bp.pw[3].get(T, True)
+        dxb = hip.conv_fwd(gs, wdd)                                                          # [K+E,7,7,C] wrt the pooled crops
+        # back across the pooling: gather at `planes` channels, then conv1's gradients on the feature map (s1 rides in the
+        # weight-gradient scale and in the prepared input-gradient weights, as for every conv of a stage)
+        N, H, W, C = feat.shape
+        dz = hip.roi_align_backward(dpre1[:K], rois, roi_start, (N, H, W, dpre1.shape[-1]), scale, sr, True)
+        hip.conv_wgrad(feat, dz, shp(w1p), s1, out=_ohwi(_grad_buf(w1p)))
+        _, w1d = bp.pw[0].get(T, True)
+        dfeat = dextra = None
+        if E:
+            hip.conv_wgrad(extra, dpre1[K:], shp(w1p), s1, out=_ohwi(_grad_buf(w1p)))
+            if ctx.needs_input_grad[9]:
+                dextra = hip.conv_fwd(dpre1[K:], w1d, residual=hip.avgpool2_bwd(dxb[K:].contiguous(), tuple(extra.shape)))
+        if ctx.needs_input_grad[0]:
+            r = hip.roi_align_backward(dxb[:K], rois, roi_start, (N, H, W, C), scale, sr, True, pooled=True)
+            dfeat = hip.conv_fwd(dz, w1d, residual=r)
+        return dfeat, None, None, None, None, None, None, None, None, dextra
+
+
+def roi_stage_supported(blocks):
+    """the commuted form needs a 1x1 conv1 and a pooled (stride-2) downsample path in the first block: CLIP's layer4"""
+    bp = blocks[0]
+    return bp.stride == 2 and bp.w[3] is not None and tuple(bp.w[0].shape[2:]) == (1, 1) and tuple(bp.w[3].shape[2:]) == (1, 1)
+
+
+def roi_stage(feat, rois, roi_start, blocks, frozen, out_size, scale, sr, extra=None, out_grad_premasked=False):
+    assert rois.dim() == 2 and rois.size(1) == 5 and out_size % 2 == 0                     # layers/roi_align.py:55
+    assert extra is None or tuple(extra.shape[1:]) == (out_size, out_size, feat.shape[3])
+    if frozen or not torch.is_grad_enabled():
+        cur = _roi_block0_forward(feat.contiguous(), rois, blocks[0], out_size, scale, sr, extra)[4]
+        for bp in blocks[1:]:
+            cur, _ = _block_forward(cur, bp, False)
+        return cur
+    return RoIStageFn.apply(feat, blocks[0].w[0], rois, roi_start, blocks, out_size, scale, sr, out_grad_premasked, extra)
+
+
+def roi_stage_attnpool(feat, rois, roi_start, blocks, frozen, ap, out_size, scale, sr, extra=None):
+    """RoIAlign -> layer4 -> AttentionPool2d (clip_roi_heads.py:160-165); see ``res_stage_attnpool`` for the ReLU fusion"""
+    fuse = not frozen and torch.is_grad_enabled()
+    y = roi_stage(feat, rois, roi_start, blocks, frozen, out_size, scale, sr, extra, out_grad_premasked=fuse)
     return AttnPoolFn.apply(y, None if ap.frozen else ap.q_w, ap, fuse)
 
 

@@ -6,6 +6,7 @@ fast_rcnn.py:100-127,368-689}, modeling/poolers.py:61-95,190-229.
 query-0 attention pool (HIP) -> cosine-logit text-embedding classifier (HIP, fp32) + bbox_pred.
 """
 import math
+import os
 from typing import Dict, List
 
 import torch
@@ -30,15 +31,18 @@ class ROIPooler(nn.Module):
         assert len(scales) == 1 and pooler_type == "ROIAlignV2"
         self.output_size, self.scale, self.sampling_ratio = output_size, scales[0], sampling_ratio
 
-    def forward_nhwc(self, feat, box_lists: List[Boxes], with_pooled=False, extra_maps=None):
-        """``with_pooled``: the crops carry their 2x2-average-pooled copy for the stride-2 stage that follows (layers.roi_align);
-        ``extra_maps``: maps of the crops' geometry appended behind them"""
-        dev = feat.device
+    def rois_of(self, box_lists: List[Boxes], dev):
+        """convert_boxes_to_pooler_format poolers.py:68-95: rois grouped by image, (batch_idx, x0, y0, x1, y1); + per-image offsets"""
         counts = [len(b) for b in box_lists]
-        # convert_boxes_to_pooler_format poolers.py:68-95: rois grouped by image, (batch_idx, x0, y0, x1, y1)
         bidx = to_device_async(torch.repeat_interleave(torch.arange(len(counts), dtype=torch.float32), torch.tensor(counts)), dev)
         rois = torch.cat([bidx[:, None], torch.cat([b.tensor.float() for b in box_lists])], dim=1).contiguous()
         start = to_device_async(torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32), dev)
+        return rois, start
+
+    def forward_nhwc(self, feat, box_lists: List[Boxes], with_pooled=False, extra_maps=None):
+        """``with_pooled``: the crops carry their 2x2-average-pooled copy for the stride-2 stage that follows (layers.roi_align);
+        ``extra_maps``: maps of the crops' geometry appended behind them"""
+        rois, start = self.rois_of(box_lists, feat.device)
         return layers.roi_align(feat, rois, start, self.output_size, self.scale, self.sampling_ratio, True, with_pooled=with_pooled,
                                 extra=extra_maps)
 
@@ -58,6 +62,11 @@ class _Linear(nn.Module):
             self._pw = layers.PreparedWeight(self.weight, None, frozen=not self.weight.requires_grad)
         return self._pw
 
+
+# RoI head entry: evaluate layer4.0's conv1 on the feature map before the pooling (layers.RoIStageFn).  CDDMSL_ROI_COMMUTE=0 keeps
+# the literal order (pooler, then layer4 on the crops) -- the two are compared in tests/test_gpu_ops.py.
+def commute_roi_conv1():
+    return os.environ.get("CDDMSL_ROI_COMMUTE", "1") != "0"
 
 NMS_MAX_CANDIDATES = 12288      # cddmsl_nms handles 192 mask words of 64 boxes per image
 
@@ -324,6 +333,12 @@ class CLIPRes5ROIHeads(nn.Module):
         they ride behind the RoI crops, the result has their embeddings in rows K.."""
         from .backbone import AttentionPool2d, ResStage
         fused = isinstance(res5, ResStage) and isinstance(attnpool, AttentionPool2d)
+        if fused and self.pooler.output_size % 2 == 0 and layers.roi_stage_supported(res5.block_params()) and commute_roi_conv1():
+            # pooler + layer4 + attention pool as one composition, the first block's conv1 evaluated on the feature map BEFORE
+            # the pooling (layers.RoIStageFn): the [K,14,14,1024] crop tensor is never formed
+            rois, start = self.pooler.rois_of(boxes, feat_nhwc.device)
+            return layers.roi_stage_attnpool(feat_nhwc, rois, start, res5.block_params(), res5[0].frozen, attnpool._params(),
+                                             self.pooler.output_size, self.pooler.scale, self.pooler.sampling_ratio, extra_maps)
         # (CLIP's layer4 is stride 2 with an AvgPool2d on the downsample path: RoIAlign hands it the pooled crops as well)
         x = self.pooler.forward_nhwc(feat_nhwc, boxes, with_pooled=fused and res5[0].stride > 1, extra_maps=extra_maps)
         if fused:

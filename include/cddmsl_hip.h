@@ -73,6 +73,20 @@ int cddmsl_roi_align_forward(const void* x, const float* rois, void* y, void* y_
 int cddmsl_roi_align_backward(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay, float* ws_ax,
                               int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw, float spatial_scale,
                               int sampling_ratio, int aligned, int dtype, void* stream);
+/* The RoI head's entry (modeling/roi_heads/clip_roi_heads.py:113-115: pooler, then backbone.layer4, whose first Bottleneck
+ * starts with a 1x1 conv and pools 2x2 on its downsample path, clip_backbone.py:45-52,57-70) with the 1x1 conv moved in FRONT of
+ * the pooling -- RoIAlign is linear over pixels, a 1x1 conv over channels: roi_align(x) W = roi_align(x W) -- so the
+ * [K][14][14][1024] crop tensor (3.3 GB at 8192 RoIs) is never formed:
+ *   _affine:  y = relu?(scale[c] * roi_align(x)[.., c] + bias[c])  (FrozenBN + ReLU of that conv; scale / bias nullable),
+ *             y nullable when only y_pooled (the downsample path's AvgPool2d(2) of the crops) is wanted;
+ *   _backward_pooled: dy is the gradient of the pooled map [K][ph][pw][C] (RoIAlign grid 2ph x 2pw): roi_align_backward of the
+ *             AvgPool2d backward of dy, without forming it. */
+int cddmsl_roi_align_forward_affine(const void* x, const float* rois, void* y, void* y_pooled, const float* scale,
+                                    const float* bias, int relu, int N, int C, int H, int W, int K, int ph, int pw,
+                                    float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
+int cddmsl_roi_align_backward_pooled(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,
+                                     float* ws_ax, int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw,
+                                     float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
 
 /* ---- RPN / matcher index stages --------------------------------------------------------------------------------
  * modeling/anchor_generator.py:161-228, modeling/box_regression.py:77-115, modeling/proposal_generator/rpn.py:514-533,

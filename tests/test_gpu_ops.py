@@ -522,3 +522,81 @@ def test_attnpool_softmax_glue(dtype, H):
     assert float(dsT[:, P1:].abs().max()) == 0.0
     assert torch.equal(pds[:, :H, :P1], p.to(dtype)) and torch.equal(pds[:, H:, :P1], dsT[:, :P1].transpose(1, 2))
     assert float(pds[:, :, P1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-3), ("bf16", 4e-2)])   # (f32: a handful of ReLU decisions at ~0 flip between the two orders)
+def test_roi_head_entry_with_conv1_in_front_of_the_pooling(dtype, tol, monkeypatch):
+    """RoIAlign -> layer4 -> attention pool with layer4.0's conv1 evaluated on the feature map BEFORE the pooling and the
+    downsample path's pooled crops written directly (layers.RoIStageFn, no [K,14,14,1024] crop tensor) against the literal order
+    of clip_roi_heads.py:113-115,160-165 (pooler, then layer4 on the crops): embeddings, the gradients wrt the feature map and
+    the appended maps, and every layer4 / attention-pool weight gradient.  Boxes include out-of-image, tiny and empty ones."""
+    import os
+    from cddmsl_amd import synthetic
+    from cddmsl_amd.config import get_cfg
+    from cddmsl_amd.modeling import build_model
+    from cddmsl_amd.structures import Boxes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(root, "configs", "VOC-Experiments", "faster_rcnn_CLIP_R_50_C4.yaml"))
+    cfg.merge_from_list(["MODEL.COMPUTE_DTYPE", dtype])
+    model = build_model(cfg)
+    model.load_state_dict(synthetic.make_state_dict(0), strict=False)
+    model.train()
+    T = model.compute_dtype
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 13, 21
+    boxes = []
+    for n in range(N):
+        k = 9 + 4 * n
+        x0, y0 = torch.rand(k, generator=g) * W * 16 * 0.8 - 20, torch.rand(k, generator=g) * H * 16 * 0.8 - 20
+        b = torch.stack([x0, y0, x0 + 8 + torch.rand(k, generator=g) * 250, y0 + 8 + torch.rand(k, generator=g) * 180], dim=1)
+        b[0] = torch.tensor([30.0, 30.0, 30.0, 30.0])            # empty box
+        b[1] = torch.tensor([5.0, 5.0, 9.0, 8.0])                # smaller than one bin
+        boxes.append(Boxes(b.cuda()))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CDDMSL_ROI_COMMUTE", mode)
+        model.zero_grad(set_to_none=True)
+        feat = (_rand((N, H, W, 1024), 31).relu()).to(T).cuda().requires_grad_(True)
+        extra = (_rand((3, 14, 14, 1024), 32).relu()).to(T).cuda().requires_grad_(True)
+        out = model.roi_heads._pooled_embeddings(feat, boxes, model.backbone.layer4, model.backbone.attnpool, extra)
+        assert tuple(out.shape) == (sum(len(b) for b in boxes) + 3, 1024) and out.dtype == torch.float32
+        (out * _rand(tuple(out.shape), 33).cuda()).sum().backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()
+                 if p.grad is not None and (k.startswith("backbone.layer4.") or k.startswith("backbone.attnpool."))}
+        res[mode] = (out.detach().cpu(), feat.grad.float().cpu(), extra.grad.float().cpu(), grads)
+    a, b = res["0"], res["1"]
+    rel = lambda u, v: float((u - v).abs().max() / max(float(v.abs().max()), 1e-6))
+    assert rel(b[0], a[0]) < tol and rel(b[1], a[1]) < tol and rel(b[2], a[2]) < tol, (rel(b[0], a[0]), rel(b[1], a[1]), rel(b[2], a[2]))
+    assert set(a[3]) == set(b[3]) and "backbone.layer4.0.conv1.weight" in a[3] and "backbone.layer4.0.downsample.0.weight" in a[3]
+    for k in a[3]:
+        if float(a[3][k].abs().max()) < 1e-7:
+            continue
+        assert rel(b[3][k], a[3][k]) < tol, (k, rel(b[3][k], a[3][k]))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
+def test_roi_align_affine_and_pooled_entry_points(dtype, tol):
+    """cddmsl_roi_align_forward_affine / _backward_pooled against compositions of the plain entry points: relu(s*roi_align(x)+b),
+    the pooled-only output = avgpool2 of the crops, and the pooled backward = roi_align_backward(avgpool2_bwd(dy))."""
+    from cddmsl_amd import hip
+    N, C, H, W, K = 2, 64, 11, 17, 23
+    g = torch.Generator().manual_seed(9)
+    x = _rand((N, H, W, C), 41).to(dtype).cuda()
+    bi = torch.sort(torch.randint(0, N, (K,), generator=g)).values.float()
+    x0, y0 = torch.rand(K, generator=g) * W * 16 * 0.9 - 10, torch.rand(K, generator=g) * H * 16 * 0.9 - 10
+    rois = torch.stack([bi, x0, y0, x0 + 4 + torch.rand(K, generator=g) * 200, y0 + 4 + torch.rand(K, generator=g) * 150], dim=1).cuda()
+    start = torch.tensor([0, int((bi == 0).sum()), K], dtype=torch.int32).cuda()
+    sc, bs = (torch.rand(C, generator=g) + 0.5).cuda(), (_rand((C,), 42, 0.3)).cuda()
+    plain, pooled = hip.roi_align_forward(x, rois, 14, 14, 1 / 16, 0, True, with_pooled=True)
+    y = hip.roi_align_forward_affine(x, rois, 14, 14, 1 / 16, 0, True, sc, bs, relu=True)
+    # the affine is applied to the unrounded pooled value; the reference composition rounds the crop first
+    ref = torch.relu(plain.float() * sc + bs)
+    assert float((y.float() - ref).abs().max()) <= tol * float(ref.abs().max())
+    yp = hip.roi_align_forward_affine(x, rois, 14, 14, 1 / 16, 0, True, pooled_only=True)
+    assert torch.equal(yp, pooled)
+    dy = _rand((K, 7, 7, C), 43).to(dtype).cuda()
+    want = hip.roi_align_backward(hip.avgpool2_bwd(dy, (K, 14, 14, C)), rois, start, (N, H, W, C), 1 / 16, 0, True)
+    got = hip.roi_align_backward(dy, rois, start, (N, H, W, C), 1 / 16, 0, True, pooled=True)
+    assert float((got.float() - want.float()).abs().max()) <= tol * float(want.float().abs().max())
