@@ -38,9 +38,17 @@ def init_distributed(backend=None):
 
 
 class GradBuckets:
-    """DDP-style gradient averaging (engine/defaults.py:74): all trainable grads live in one flat f32 buffer
-    (each ``p.grad`` is a view with the parameter's memory layout), all-reduced in a few large RCCL calls --
-    xGMI rings are per-link bound, so few big messages beat DDP's 25 MB default buckets."""
+    """DDP-style gradient averaging (engine/defaults.py:72-74): all trainable grads live in one flat f32 buffer (each ``p.grad``
+    is a view with the parameter's memory layout), all-reduced in a few large RCCL calls -- xGMI rings are per-link bound, so
+    few big messages beat DDP's 25 MB default buckets.
+
+    Overlap with backward (what the reference's DDP reducer does): the weight-gradient kernels ACCUMULATE into the flat buffer,
+    and every such launch is announced through ``layers._grad_buf``.  The first step of a given step signature runs the plain
+    way and counts the announcements per parameter; later steps count down, and when every parameter overlapping a bucket has
+    had its last write enqueued, an event is recorded on the compute stream and the bucket's all-reduce starts on a side stream
+    behind it -- while backward continues with the earlier layers.  Buckets still open when backward returns (the backbone's
+    first stages, written last) are reduced then.  A write into a bucket that is already on the wire would corrupt the step, so
+    it raises (``CDDMSL_OVERLAP_ALLREDUCE=0`` switches the overlap off)."""
 
     def __init__(self, params, bucket_bytes=64 << 20):
         self.params = [p for p in params if p.requires_grad]
@@ -48,6 +56,7 @@ class GradBuckets:
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         off = 0
+        spans = []
         for p in self.params:
             n = p.numel()
             chunk = self.flat[off:off + n]
@@ -58,21 +67,115 @@ class GradBuckets:
                 g = chunk.view(p.shape)
             assert same_layout(g, p), (g.stride(), p.stride(), p.shape)
             p.grad = g
+            spans.append((off, off + n))
             off += n
         per = max(bucket_bytes // 4, 1)
         self.buckets = [self.flat[i:i + per] for i in range(0, total, per)]
+        # parameters overlapping each bucket, and the buckets of each parameter
+        self._bucket_params = [[] for _ in self.buckets]
+        self._param_buckets = {}
+        for p, (a, b) in zip(self.params, spans):
+            bs = list(range(a // per, (max(b, a + 1) - 1) // per + 1))
+            self._param_buckets[id(p)] = bs
+            for bi in bs:
+                self._bucket_params[bi].append(id(p))
+        self.overlap = os.environ.get("CDDMSL_OVERLAP_ALLREDUCE", "1") != "0"
+        self._expected = {}           # step signature -> {id(param): number of gradient writes per step}
+        self._counting = None         # dict being filled during a counting step
+        self._left = None             # per-parameter writes still to come (overlapped step)
+        self._open = None             # per-bucket number of parameters not finished yet
+        self._launched, self._ready, self._handles = set(), [], []
+        self._comm_stream = None
+        self.launch_log = []          # (bucket, writes announced so far) per step: when each bucket went on the wire
+        self._announced, self._sig = 0, None
 
     def zero(self):
         self.flat.zero_()
 
+    # ---------------------------------------------------------------- overlap machinery
+    def begin_backward(self, signature):
+        """Call right before ``backward()``.  world size 1: nothing to do."""
+        from . import layers
+        self._handles, self._launched, self._ready, self.launch_log, self._announced = [], set(), [], [], 0
+        if get_world_size() == 1 or not self.overlap:
+            self._left = self._counting = None
+            return
+        exp = self._expected.get(signature)
+        if exp is None:                                   # first step of this kind: count, reduce after backward
+            self._counting, self._left = {}, None
+            self._sig = signature
+        else:
+            self._counting = None
+            self._left = dict(exp)
+            self._open = [sum(1 for q in ps if exp.get(q, 0) > 0) for ps in self._bucket_params]
+        layers._TOUCH_HOOK[0] = self._on_touch
+
+    def _on_touch(self, p):
+        self._announced += 1
+        if self._counting is not None:
+            self._counting[id(p)] = self._counting.get(id(p), 0) + 1
+            return
+        # the launches announced by EARLIER calls are in the queue by now: buckets they completed can go
+        self._flush_ready()
+        k = id(p)
+        if k not in self._left:
+            return
+        for bi in self._param_buckets[k]:
+            if bi in self._launched:
+                raise RuntimeError("GradBuckets: a gradient was written into a bucket whose all-reduce is already in flight (the "
+                                   "step's kernel sequence changed); rerun with CDDMSL_OVERLAP_ALLREDUCE=0")
+        self._left[k] -= 1
+        if self._left[k] == 0:
+            for bi in self._param_buckets[k]:
+                self._open[bi] -= 1
+                if self._open[bi] == 0:
+                    self._ready.append(bi)
+
+    def _flush_ready(self):
+        while self._ready:
+            self._launch(self._ready.pop(0))
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        ws = get_world_size()
+        self._launched.add(bi)
+        self.launch_log.append((bi, self._announced))
+        if b.is_cuda:
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=b.device)
+            ev = torch.cuda.Event()
+            ev.record()                                   # behind every launch enqueued so far on the compute stream
+            with torch.cuda.stream(self._comm_stream):
+                self._comm_stream.wait_event(ev)
+                b.mul_(1.0 / ws)
+                self._handles.append(dist.all_reduce(b, async_op=True))
+        else:
+            b.mul_(1.0 / ws)
+            self._handles.append(dist.all_reduce(b, async_op=True))
+
     def all_reduce_mean(self):
+        """After ``backward()`` returned: start what is not on the wire yet, wait for everything."""
+        from . import layers
+        layers._TOUCH_HOOK[0] = None
         ws = get_world_size()
         if ws == 1:
             return
-        self.flat.mul_(1.0 / ws)
-        handles = [dist.all_reduce(b, async_op=True) for b in self.buckets]
-        for h in handles:
-            h.wait()
+        if self._counting is not None:
+            self._expected[self._sig] = self._counting
+            self._counting = None
+        if self._left is not None and any(v != 0 for v in self._left.values()):
+            late = [bi for bi in self._launched if any(self._left.get(q, 0) != 0 for q in self._bucket_params[bi])]
+            if late:
+                raise RuntimeError("GradBuckets: fewer gradient writes than expected reached buckets already reduced")
+        self._ready = []
+        for bi in range(len(self.buckets)):
+            if bi not in self._launched:
+                self._launch(bi)
+        for h in self._handles:
+            h.wait()                                      # (NCCL: the compute stream waits for the collective's stream)
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._handles, self._left = [], None
 
 
 class SimpleTrainer:
@@ -132,6 +235,9 @@ class SimpleTrainer:
         self.buckets.zero()                       # model.zero_grad() / optimizer.zero_grad()
         loss_dict = self.compute_losses(data)
         losses = sum(loss_dict.values())
+        # (the kernel sequence of backward depends on which branches are live and how they are composed, nothing else)
+        self.buckets.begin_backward((self.iter > self.burn_in, self.share_source_pass, self.fuse_consistency,
+                                     bool(self.cfg.MODEL.KD_REGULRAZIATION), len(data), tuple(sorted(loss_dict))))
         losses.backward()
         self.buckets.all_reduce_mean()
         self.optimizer.iteration = self.iter

@@ -39,10 +39,17 @@ def load_generation():
 _TOUCHED = set()   # ids of parameters that received a gradient this step (SGD skips grad-less parameters)
 
 
+_TOUCH_HOOK = [None]   # callable(param) run at every gradient-buffer hand-out (engine.GradBuckets: all-reduce overlapped with backward)
+
+
 def _grad_buf(p):
+    """The buffer a weight-gradient kernel accumulates into.  Every write of a parameter gradient on the hot path goes through
+    here, immediately before the launch that writes it: the one place that knows the order in which gradients are produced."""
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
     _TOUCHED.add(id(p))
+    if _TOUCH_HOOK[0] is not None:
+        _TOUCH_HOOK[0](p)
     return p.grad
 
 

@@ -166,3 +166,73 @@ def test_eval_only_two_ranks_equals_one_rank(tmp_path):
     for k in one:
         assert (one[k] != one[k] and two[k] != two[k]) or abs(one[k] - two[k]) < 1e-12, (k, one[k], two[k])
     assert any(v == v and v > 0 for v in one.values()), one
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gradient all-reduce overlapped with backward (engine/defaults.py:72-74: the DDP reducer fires a bucket when its last gradient
+# is ready): same averaged gradients as the plain post-backward reduction, buckets on the wire before backward has finished
+def _overlap_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cddmsl_amd import layers
+        from cddmsl_amd.engine import GradBuckets
+        g = torch.Generator().manual_seed(7)
+        shapes = [(8, 4, 3, 3), (16,), (12, 8), (6, 4, 1, 1), (40,), (5, 5)]
+        params = [torch.nn.Parameter(torch.zeros(*s).contiguous(memory_format=torch.channels_last) if len(s) == 4 else torch.zeros(*s)) for s in shapes]
+        gb = GradBuckets(params, bucket_bytes=4 * 100)           # 100 floats per bucket: several parameters per bucket, some straddling
+        assert len(gb.buckets) >= 4
+        # one "backward": parameters written in reverse registration order, two of them twice (a shared backbone)
+        order = [5, 4, 3, 2, 3, 1, 0, 1]
+        contrib = {r: [torch.randn(*shapes[i], generator=g) for i in order] for r in range(world)}   # both ranks draw the same stream
+
+        def backward():
+            for i, c in zip(order, contrib[rank]):
+                layers._grad_buf(params[i]).add_(c)
+
+        want = [torch.zeros(*s) for s in shapes]
+        for r in range(world):
+            for i, c in zip(order, contrib[r]):
+                want[i] += c / world
+        logs = []
+        for step in range(3):
+            gb.zero()
+            gb.begin_backward(("sig",))
+            backward()
+            gb.all_reduce_mean()
+            for p, w in zip(params, want):
+                assert torch.allclose(p.grad, w, atol=1e-6), step
+            logs.append(list(gb.launch_log))
+        total = len(order)
+        assert all(a == total for _, a in logs[0])                                   # counting step: everything after backward
+        assert any(a < total for _, a in logs[1]) and logs[1] == logs[2]             # overlapped: buckets leave while writes remain
+        assert sorted(b for b, _ in logs[1]) == list(range(len(gb.buckets)))         # every bucket exactly once
+        # another step signature is counted afresh; a changed kernel sequence under a known signature fails loudly
+        gb.zero()
+        gb.begin_backward(("other",))
+        backward()
+        layers._grad_buf(params[5]).add_(1.0)
+        gb.all_reduce_mean()
+        gb.zero()
+        gb.begin_backward(("sig",))
+        backward()
+        try:
+            layers._grad_buf(params[5]).add_(1.0)                                    # params[5]'s bucket left long ago
+            layers._grad_buf(params[5]).add_(1.0)
+            raised = False
+        except RuntimeError:
+            raised = True
+        layers._TOUCH_HOOK[0] = None
+        for h in gb._handles:
+            h.wait()
+        assert raised
+        ret[rank] = logs[1]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_overlaps_backward_world2():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_overlap_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert len(ret) == 2 and ret[0] == ret[1]

@@ -524,12 +524,7 @@ def test_attnpool_softmax_glue(dtype, H):
     assert float(pds[:, :, P1:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 2e-3), ("bf16", 4e-2)])   # (f32: a handful of ReLU decisions at ~0 flip between the two orders)
-def test_roi_head_entry_with_conv1_in_front_of_the_pooling(dtype, tol, monkeypatch):
-    """RoIAlign -> layer4 -> attention pool with layer4.0's conv1 evaluated on the feature map BEFORE the pooling and the
-    downsample path's pooled crops written directly (layers.RoIStageFn, no [K,14,14,1024] crop tensor) against the literal order
-    of clip_roi_heads.py:113-115,160-165 (pooler, then layer4 on the crops): embeddings, the gradients wrt the feature map and
-    the appended maps, and every layer4 / attention-pool weight gradient.  Boxes include out-of-image, tiny and empty ones."""
+def _roi_entry_run(dtype, mode, monkeypatch):
     import os
     from cddmsl_amd import synthetic
     from cddmsl_amd.config import get_cfg
@@ -553,27 +548,45 @@ def test_roi_head_entry_with_conv1_in_front_of_the_pooling(dtype, tol, monkeypat
         b[0] = torch.tensor([30.0, 30.0, 30.0, 30.0])            # empty box
         b[1] = torch.tensor([5.0, 5.0, 9.0, 8.0])                # smaller than one bin
         boxes.append(Boxes(b.cuda()))
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("CDDMSL_ROI_COMMUTE", mode)
-        model.zero_grad(set_to_none=True)
-        feat = (_rand((N, H, W, 1024), 31).relu()).to(T).cuda().requires_grad_(True)
-        extra = (_rand((3, 14, 14, 1024), 32).relu()).to(T).cuda().requires_grad_(True)
-        out = model.roi_heads._pooled_embeddings(feat, boxes, model.backbone.layer4, model.backbone.attnpool, extra)
-        assert tuple(out.shape) == (sum(len(b) for b in boxes) + 3, 1024) and out.dtype == torch.float32
-        (out * _rand(tuple(out.shape), 33).cuda()).sum().backward()
-        torch.cuda.synchronize()
-        grads = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()
-                 if p.grad is not None and (k.startswith("backbone.layer4.") or k.startswith("backbone.attnpool."))}
-        res[mode] = (out.detach().cpu(), feat.grad.float().cpu(), extra.grad.float().cpu(), grads)
-    a, b = res["0"], res["1"]
+    monkeypatch.setenv("CDDMSL_ROI_COMMUTE", mode)
+    feat = (_rand((N, H, W, 1024), 31).relu()).bfloat16().to(T).cuda().requires_grad_(True)    # (bf16-representable inputs for both dtypes)
+    extra = (_rand((3, 14, 14, 1024), 32).relu()).bfloat16().to(T).cuda().requires_grad_(True)
+    out = model.roi_heads._pooled_embeddings(feat, boxes, model.backbone.layer4, model.backbone.attnpool, extra)
+    assert tuple(out.shape) == (sum(len(b) for b in boxes) + 3, 1024) and out.dtype == torch.float32
+    (out * _rand(tuple(out.shape), 33).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()
+             if p.grad is not None and (k.startswith("backbone.layer4.") or k.startswith("backbone.attnpool."))}
+    grads["(embeddings)"], grads["(d feature map)"], grads["(d appended maps)"] = out.detach().cpu(), feat.grad.float().cpu(), extra.grad.float().cpu()
+    return grads
+
+
+def test_roi_head_entry_with_conv1_in_front_of_the_pooling(monkeypatch):
+    """RoIAlign -> layer4 -> attention pool with layer4.0's conv1 evaluated on the feature map BEFORE the pooling and the
+    downsample path's pooled crops written directly (layers.RoIStageFn, no [K,14,14,1024] crop tensor) against the literal order
+    of clip_roi_heads.py:113-115,160-165 (pooler, then layer4 on the crops): embeddings, the gradients wrt the feature map and
+    the appended maps, and every layer4 / attention-pool weight gradient.  Boxes include out-of-image, tiny and empty ones.
+    Exact f32: the two orders agree to 2e-3 of each tensor's max (a handful of ReLU decisions at ~0 flip).  bf16: both orders are
+    compared with the f32 result -- the commuted one must be as close as the literal one (it rounds the conv1 map instead of the
+    crops, and the gathered gradient instead of the crop gradient)."""
     rel = lambda u, v: float((u - v).abs().max() / max(float(v.abs().max()), 1e-6))
-    assert rel(b[0], a[0]) < tol and rel(b[1], a[1]) < tol and rel(b[2], a[2]) < tol, (rel(b[0], a[0]), rel(b[1], a[1]), rel(b[2], a[2]))
-    assert set(a[3]) == set(b[3]) and "backbone.layer4.0.conv1.weight" in a[3] and "backbone.layer4.0.downsample.0.weight" in a[3]
-    for k in a[3]:
-        if float(a[3][k].abs().max()) < 1e-7:
+    lit = _roi_entry_run("f32", "0", monkeypatch)
+    com = _roi_entry_run("f32", "1", monkeypatch)
+    assert set(lit) == set(com) and "backbone.layer4.0.conv1.weight" in lit and "backbone.layer4.0.downsample.0.weight" in lit
+    for k in lit:
+        if float(lit[k].abs().max()) >= 1e-7:
+            assert rel(com[k], lit[k]) < 2e-3, (k, rel(com[k], lit[k]))
+    lit16 = _roi_entry_run("bf16", "0", monkeypatch)
+    com16 = _roi_entry_run("bf16", "1", monkeypatch)
+    worst = (0.0, 0.0, None)
+    for k in lit:
+        if float(lit[k].abs().max()) < 1e-7:
             continue
-        assert rel(b[3][k], a[3][k]) < tol, (k, rel(b[3][k], a[3][k]))
+        e_lit, e_com = rel(lit16[k], lit[k]), rel(com16[k], lit[k])
+        if e_com > worst[1]:
+            worst = (e_lit, e_com, k)
+        assert e_com < 1.5 * e_lit + 1e-2, (k, e_lit, e_com)      # (as close to f32 as the literal order, tensor by tensor)
+    print("bf16 error vs exact f32 (literal order, commuted order, tensor), worst commuted:", worst)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
