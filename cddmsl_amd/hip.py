@@ -111,17 +111,18 @@ class _Profiler:
         e1.record()
         self.events.append((name, flops, e0, e1, nbytes))
         if shape is not None:
-            self.shapes.append((name, shape, flops, e0, e1))
+            self.shapes.append((name, shape, flops, e0, e1, nbytes))
 
     def by_shape(self):
-        """(name, shape) -> [launches, ms, flops]; call before collect()."""
+        """(name, shape) -> [launches, ms, flops, algorithmic bytes]; call before collect()."""
         torch.cuda.synchronize()
         out = {}
-        for name, shape, flops, e0, e1 in self.shapes:
-            d = out.setdefault((name, shape), [0, 0.0, 0.0])
+        for name, shape, flops, e0, e1, nbytes in self.shapes:
+            d = out.setdefault((name, shape), [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1)
             d[2] += flops
+            d[3] += nbytes
         return out
 
     def collect(self):

@@ -1,39 +1,73 @@
 #!/bin/bash
-# Collects the judged profiling artefacts on the GPU box (run through gpurun from the repo root):
-#   1. rocprofv3 --kernel-trace --stats of the default bench command   -> gpurun_out/prof/<tag>_kernel_stats.csv
-#   2. HBM traffic PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs; MI355X_MICROARCH.md: TCC has 4 slots,
-#      FETCH_SIZE costs 3, WRITE_SIZE 2) and the per-launch average for the dominant kernel, with the gfx950
-#      correction FETCH_SIZE x2 for wide coalesced reads -> gpurun_out/prof/<tag>_traffic.json
-# usage: bash tools/profile_round.sh r01
+# Collects the judged profiling artefacts on the GPU box (run through gpurun from the repo root), named per round:
+#   1. rocprofv3 --kernel-trace --stats of the default bench command            -> <tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json
+#   2. PMC passes, each in its own run with --kernel-trace only (MI355X_MICROARCH.md "rocprofv3 PMC slots": TCC has 4 slots,
+#      FETCH_SIZE costs 3, WRITE_SIZE 2; SQ and GRBM are independent blocks):
+#        FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+#      -> <tag>_traffic.json : per GEMM kernel HBM bytes per launch (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), MFMA-busy share of
+#         the kernel's SIMD cycles (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)), effective clock
+#         (GRBM_GUI_ACTIVE / 8 / duration; rocprofv3 sums the 8 XCDs) of its long dispatches
+#   3. tools/shape_profile.py                                                   -> <tag>_shape_profile.txt
+#   4. tools/clock_probe.hip (in-kernel clock of an MFMA-dense loop)            -> <tag>_clock_probe.txt
+# usage: bash tools/profile_round.sh r02
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
+B="--steps 2 --warmup 1 --no-cpu-baseline --no-forward-roofline"
 cd /tmp && export TMPDIR=/tmp
-rm -rf $OUT/stats $OUT/fetch $OUT/write
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-forward-roofline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.err
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-forward-roofline > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-forward-roofline > /dev/null 2> $OUT/write.err
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py $B > /dev/null 2> $OUT/fetch.err
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py $B > /dev/null 2> $OUT/write.err
+echo "write done"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -- python3 $R/bench.py $B > /dev/null 2> $OUT/sq.err
+echo "sq done"
 cd $R
 python3 - <<PY
 import csv, glob, json, collections
-def per_launch(tag, counter, kern):
+def table(tag):
     f = glob.glob('$OUT/%s/*/*counter_collection.csv' % tag)[0]
+    rows = list(csv.DictReader(open(f)))
+    return rows
+def per_launch(rows, counter, kern):
     tot, ids = 0.0, set()
-    for r in csv.DictReader(open(f)):
+    for r in rows:
         if kern in r['Kernel_Name'] and r['Counter_Name'] == counter:
             tot += float(r['Counter_Value']); ids.add(r['Dispatch_Id'])
     return tot / max(len(ids), 1), len(ids)
+fetch, write, sq = table("fetch"), table("write"), table("sq")
+# durations of the sq pass's dispatches (kernel trace of the same run)
+kt = glob.glob('$OUT/sq/*/*kernel_trace.csv')[0]
+dur = {r['Dispatch_Id']: (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) for r in csv.DictReader(open(kt))}
 out = {}
 for kern, name in (("k_conv_fwd256", "k_conv_fwd256"), ("k_conv_fwdI", "k_conv_fwd"), ("k_wgrad256", "k_wgrad256"), ("k_conv_wgrad_dma", "k_conv_wgrad_dma")):
-    fk, n1 = per_launch("fetch", "FETCH_SIZE", kern)      # KiB per launch
-    wk, n2 = per_launch("write", "WRITE_SIZE", kern)
+    fk, n1 = per_launch(fetch, "FETCH_SIZE", kern)      # KiB per launch
+    wk, n2 = per_launch(write, "WRITE_SIZE", kern)
+    per = collections.defaultdict(dict)
+    for r in sq:
+        if kern in r['Kernel_Name']:
+            per[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
+    mf = sum(v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) for v in per.values())
+    gui = sum(v.get('GRBM_GUI_ACTIVE', 0.0) for v in per.values())
+    sqb = sum(v.get('SQ_BUSY_CYCLES', 0.0) for v in per.values())
+    long_ = [(v['GRBM_GUI_ACTIVE'] / 8.0) / dur[d] for d, v in per.items() if d in dur and dur[d] > 1.0e6 and 'GRBM_GUI_ACTIVE' in v]
     out[name] = {"launches_sampled": n1, "fetch_size_kib_raw": fk, "write_size_kib": wk,
                  "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0,
-                 "note": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as read"}
+                 "mfma_busy_cycles": mf, "grbm_gui_active": gui, "sq_busy_cycles": sqb,
+                 "mfma_busy_share_of_simd_cycles": (mf / (1024.0 * gui / 8.0)) if gui else None,
+                 "effective_clock_ghz_dispatches_over_1ms": (sum(long_) / len(long_)) if long_ else None, "long_dispatches": len(long_),
+                 "note": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE as read; "
+                         "MFMA share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE / 8 / dispatch duration (ns)"}
 json.dump(out, open('$OUT/${TAG}_traffic.json', 'w'), indent=1)
 print(json.dumps(out))
 PY
-head -c 600 $OUT/${TAG}_bench_under_rocprof.json; echo
+python3 tools/shape_profile.py 16 > $OUT/${TAG}_shape_profile.txt 2> $OUT/shape.err
+echo "shape profile done"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/clock_probe.hip -o /tmp/clock_probe 2> /dev/null && /tmp/clock_probe > $OUT/${TAG}_clock_probe.txt
+cat $OUT/${TAG}_clock_probe.txt
+head -c 400 $OUT/${TAG}_bench_under_rocprof.json; echo
