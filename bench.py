@@ -116,7 +116,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8 = BASELINE.json configs[4]: e4m3 forward GEMMs (MFMA-bound convs of layer3/4, RoI layer4, RPN; region x text "
+                         "contraction), bf16 elsewhere and in backward; use with --batch 32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-forward-roofline", action="store_true", help="skip the extra forward-only loop (profiling runs: keeps the kernel mix = the timed steps)")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -178,7 +180,7 @@ def main():
         tr.run_step()
     if args.warmup > 0:
         full = hip.PROFILE.collect()
-    gemm_names = ("k_conv_fwd256", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma")
+    gemm_names = ("k_conv_fwd256", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma") if args.dtype != "fp8" else ("k_conv_fwd256_fp8",)
     dom_name = "k_conv_fwd256"
     if full:
         rows = [k for k in gemm_names if k in full]
@@ -238,10 +240,10 @@ def main():
         # HBM traffic per launch of that kernel from the PMC passes (tools/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if args.batch == 16 and args.dtype == "bf16" and os.path.exists(tpath):
+        if args.batch == 16 and args.dtype == "bf16" and os.path.exists(tpath):   # (measured for the bf16 workload only)
             traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        peak = {"bf16": 2500.0, "fp8": 5000.0}.get(args.dtype, 157.3)
         # the dominant kernel serves layers on both sides of the ridge: each launch is booked under ITS bound (the larger of
         # 2MNK / MFMA peak and algorithmic bytes / HBM peak) and the two groups are reported against their own roofline
         split = {"mfma": [0, 0.0, 0.0, 0.0], "hbm": [0, 0.0, 0.0, 0.0]}
@@ -267,7 +269,8 @@ def main():
                                    f"{args.height}x{args.width}, synthetic pixels + seeded random weights",
                        "global_batch": gb, "parallelism": f"dp{world}",
                        "shared_source_pass": bool(tr.share_source_pass), "fused_consistency_mapper_pass": bool(tr.fuse_consistency)},
-            "roofline": {"bound": "mfma", "kernel": dom_name + " (implicit-GEMM conv / linear, forward + input-gradient)", "achieved": ach,
+            "roofline": {"bound": "mfma", "kernel": dom_name + (" (implicit-GEMM conv / linear, forward + input-gradient)" if args.dtype != "fp8" else
+                                                                 " (e4m3 implicit-GEMM conv, forward; v_mfma_scale_f32_32x32x64_f8f6f4)"), "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r02_traffic.json)",
                          "by_bound": by_bound,

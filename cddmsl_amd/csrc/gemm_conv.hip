@@ -51,7 +51,15 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return 
 // multiply and add (this file is built with -ffp-contract=off); the bf16 ones use one fused multiply-add -- one vector-ALU
 // operation less per output element in every epilogue, identical where scale = 1 and bias = 0 (input-gradient launches).
 template <typename T> __device__ __forceinline__ float affine(float v, float sc, float bi) {
-  return sizeof(T) == 2 ? __builtin_fmaf(v, sc, bi) : v * sc + bi;
+  return sizeof(T) <= 2 ? __builtin_fmaf(v, sc, bi) : v * sc + bi;
+}
+
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);       // e4m3fn has no infinity: saturate
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
 }
 
 struct ConvArgs {
@@ -71,6 +79,11 @@ struct ConvArgs {
   FastDiv dWo, dHo, dcpp, dKW;
   int xrs, wrs;    // row strides in 16-byte chunks: A pixel -> pixel (default cpp), B row -> row (default Kc)
   long bx, bw, by; // byte strides of the batch axis (gridDim.y); 0 for plain convolutions
+  // fp8 configuration: a second, OCP e4m3 copy of the (bf16) output for the convolution that consumes it -- y8[m][n] =
+  // sat(y * q8[0]) -- written by the 256x256 kernel's epilogue, which also max-es |y| into amax8[blockIdx & 63] (delayed scaling)
+  char* y8 = nullptr;
+  const float* q8 = nullptr;
+  unsigned* amax8 = nullptr;
 #ifdef CDDMSL_STAMPS
   unsigned long long* stamps;   // diagnostic build only (scratch/k256.hip): per-wave cycle sums of the phase segments
 #endif
@@ -98,6 +111,41 @@ template <> struct Mma<float> {
   }
   __device__ static __forceinline__ float load(const char* p) { return *(const float*)p; }
   __device__ static __forceinline__ void store(char* p, float v) { *(float*)p = v; }
+};
+
+// OCP e4m3 operands (BASELINE.json configs[4]): a 16-byte chunk holds 16 elements, one block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 (E8M0 scales fixed at 2^0: per-tensor scales are folded into the epilogue's per-channel scale by
+// the host) consumes TWO chunks per lane = 64 elements of K: twice the K per matrix-pipe cycle of the bf16 form.  The epilogue
+// (output, residual, ReLU mask) stays bf16: ES below is the epilogue's element size.  Lane half h of a step holds chunks
+// (2s' + h) for s' in the step's pair -- the same bytes for A and B, which is all a dot product needs.
+struct fp8e4 { unsigned char v; };
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+template <> struct Mma<fp8e4> {
+  static constexpr int ES = 2;
+  __device__ static __forceinline__ void step2(f32x16& acc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1) {
+    const i32x8 a = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+    const i32x8 b = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  }
+};
+// one 64x32 quadrant of a K-tile (4 chunk pairs per row): two row tiles x the tile's k-steps
+template <typename T> struct MmaQuad {
+  __device__ static __forceinline__ void run(f32x16& c0, f32x16& c1, const u32x4 (*fa)[4], const u32x4* fb) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Mma<T>::step(c0, fa[0][ks], fb[ks]);
+      Mma<T>::step(c1, fa[1][ks], fb[ks]);
+    }
+  }
+};
+template <> struct MmaQuad<fp8e4> {
+  __device__ static __forceinline__ void run(f32x16& c0, f32x16& c1, const u32x4 (*fa)[4], const u32x4* fb) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Mma<fp8e4>::step2(c0, fa[0][2 * s], fa[0][2 * s + 1], fb[2 * s], fb[2 * s + 1]);
+      Mma<fp8e4>::step2(c1, fa[1][2 * s], fa[1][2 * s + 1], fb[2 * s], fb[2 * s + 1]);
+    }
+  }
 };
 
 // 8 consecutive elements (16 B of bf16 / 32 B of f32) -> floats
@@ -1775,11 +1823,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) adb[ks] ^= 1u << 16;
   };
-#define CDDMSL_MMA_QUAD(I, J, FA, FB)                                               \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                \
-    Mma<T>::step(acc[2 * (I)][J], FA[0][ks], FB[ks]);                               \
-    Mma<T>::step(acc[2 * (I) + 1][J], FA[1][ks], FB[ks]);                           \
-  }
+#define CDDMSL_MMA_QUAD(I, J, FA, FB) MmaQuad<T>::run(acc[2 * (I)][J], acc[2 * (I) + 1][J], FA, FB)
 #ifdef CDDMSL_STAMPS   // segment sums: 0 load section, 1 first barrier + LDS wait, 2 MFMAs, 3 second barrier
   unsigned long long st_sum[4] = {0, 0, 0, 0}, st_last = 0;
 #define CDDMSL_STAMP(K) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long tt_ = __builtin_readcyclecounter(); \
@@ -1909,6 +1953,11 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   };
   const unsigned vy = (unsigned)(((wr * 128 + rr) * p.ldy + n) * eso);
   const unsigned vr = (unsigned)(((wr * 128 + rr) * p.ldr + n) * esr), vm = (unsigned)(((wr * 128 + rr) * p.ldm + n) * ES);
+  const bool emit8 = ES == 2 && p.y8 != nullptr;
+  const __amdgpu_buffer_rsrc_t ry8 = mk(p.y8, p.ldy, 1);
+  const unsigned vy8 = (unsigned)((wr * 128 + rr) * p.ldy + n);
+  const float q8s = emit8 && p.q8 ? p.q8[0] : 1.f;
+  float am8 = 0.f;
   // bf16: residual / mask rows are fetched TWO passes ahead (two register sets, static indices): with one block per CU
   // nothing else hides their HBM latency.  The f32 parity instantiation (twice the registers per row) one pass ahead.
   constexpr int DEPTH = ES == 2 ? 2 : 1;
@@ -1998,6 +2047,12 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
         for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
       }
       const unsigned so = (unsigned)((a * 32 + 8 * i) * p.ldy * eso);
+      if (emit8) {                                  // the e4m3 copy for the consuming convolution (fp8 configuration)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) am8 = fmaxf(am8, fabsf(v[j]));
+        const u32x2 o8 = {pack4_e4m3(v[0] * q8s, v[1] * q8s, v[2] * q8s, v[3] * q8s), pack4_e4m3(v[4] * q8s, v[5] * q8s, v[6] * q8s, v[7] * q8s)};
+        __builtin_amdgcn_raw_buffer_store_b64(o8, ry8, vy8, (unsigned)((a * 32 + 8 * i) * p.ldy), 0);
+      }
       if (f32out) {
         const u32x4 o0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
         const u32x4 o1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
@@ -2019,18 +2074,26 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     // alias analysis treats them as unrelated; hoisted stores overwrote the last rows of a pass in one instantiation)
     asm volatile("" ::: "memory");
   }
+  if (emit8 && p.amax8) {                           // (rows past M contribute their bias-only values: an over-estimate at worst)
+    am8 = wave_max(am8);
+    if (lane == 0) atomicMax(p.amax8 + (blockIdx.x & 63), __float_as_uint(am8));
+  }
 }
 
 // Shapes the 256x256 kernel takes: whole 256-column tiles, K-tiles inside one filter tap, vector epilogue, <= 32 taps,
 // and enough tiles to fill the chip.  Environment CDDMSL_GEMM256 (read per launch, so one process can A/B): 0 = always the
 // 128x128 kernel, 2 = the 256x256 kernel wherever it is legal, unset/1 = the heuristic below.
+static bool gemm256_legal(const ConvArgs& a) {
+  const bool vec_ok = (a.ldy % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.relu_mask || a.ldm % 8 == 0);
+  if (a.pool || (a.cpp & 7) || (a.Cout & 255) || !vec_ok || a.KH * a.KW > 31) return false;
+  if (2 * a.pad > a.KH - 1 || 2 * a.pad > a.KW - 1) return false;   // rows of a tile must ascend in memory (per-block buffer base)
+  return true;
+}
 static bool use_gemm256(const ConvArgs& a) {
   const char* e = getenv("CDDMSL_GEMM256");
   const int mode = e ? atoi(e) : 1;
   if (mode == 0) return false;
-  const bool vec_ok = (a.ldy % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.relu_mask || a.ldm % 8 == 0);
-  if (a.pool || (a.cpp & 7) || (a.Cout & 255) || !vec_ok || a.KH * a.KW > 31) return false;
-  if (2 * a.pad > a.KH - 1 || 2 * a.pad > a.KW - 1) return false;   // rows of a tile must ascend in memory (per-block buffer base)
+  if (!gemm256_legal(a)) return false;
   if (mode == 2) return true;                                   // forced (tests)
   // (per-shape A/B inside the training step: 196 tiles (M 25088, N 512) run 1.3-1.5x faster here, 100 tiles and fewer slower)
   const long tiles = (long)((a.M + 255) / 256) * (a.Cout / 256) * g_batch_peek();
@@ -2080,10 +2143,10 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
 extern "C" int cddmsl_last_kernel(void) { return g_last_kernel; }
 extern "C" int cddmsl_plan_only(int on) { const int was = g_plan_only; g_plan_only = on; return was; }
 
-extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias,
-                               const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin,
-                               int Cout, int KH, int KW, int stride, int pad, int pool, int ldy, int ldr, int ldm,
-                               int relu, int out_f32, int dtype, void* stream) {
+static int conv_fwd_impl(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                         const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin,
+                         int Cout, int KH, int KW, int stride, int pad, int pool, int ldy, int ldr, int ldm,
+                         int relu, int out_f32, int dtype, void* y8, const float* q8, float* amax8, void* stream) {
   int es = dtype == 0 ? 2 : 4;
   if (dtype != 0 && dtype != 1) return CDDMSL_ERR_ARG;
   if (Nimg < 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0) return CDDMSL_ERR_ARG;
@@ -2113,7 +2176,69 @@ extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const floa
   a.dcpp = make_fastdiv((unsigned)a.cpp); a.dKW = make_fastdiv((unsigned)KW);
   a.xrs = a.cpp; a.wrs = a.Kc; a.bx = a.bw = a.by = 0;
   if (a.M == 0) return CDDMSL_OK;
+  if (y8) {       // e4m3 second output: bf16 launches of the 256x256 kernel only (its epilogue writes it)
+    if (dtype != 0 || (out_f32 & 1) || ldy != Cout || !use_gemm256(a)) return CDDMSL_ERR_ARG;
+    a.y8 = (char*)y8; a.q8 = q8; a.amax8 = (unsigned*)amax8;
+  }
   return dtype == 0 ? conv_fwd_launch<__bf16>(a, (hipStream_t)stream) : conv_fwd_launch<float>(a, (hipStream_t)stream);
+}
+
+extern "C" int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                               const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin,
+                               int Cout, int KH, int KW, int stride, int pad, int pool, int ldy, int ldr, int ldm,
+                               int relu, int out_f32, int dtype, void* stream) {
+  return conv_fwd_impl(x, w, y, scale, bias, residual, relu_mask, Nimg, Hi, Wi, Cin, Cout, KH, KW, stride, pad, pool, ldy, ldr, ldm,
+                       relu, out_f32, dtype, nullptr, nullptr, nullptr, stream);
+}
+
+// cddmsl_conv_fwd (bf16) that ALSO writes y8 [M][Cout] = OCP e4m3 of sat(y * q8[0]) and max-es |y| into amax8[0..63] (64 floats,
+// spread by block to keep the atomics off one address): the producer side of the fp8 configuration -- the convolution that
+// consumes y reads y8 instead of a separate quantisation pass.  Only launches the 256x256 kernel takes (CDDMSL_ERR_ARG otherwise:
+// the caller asks cddmsl_conv_fwd_q8_ok first).
+extern "C" int cddmsl_conv_fwd_q8(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                                  const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin,
+                                  int Cout, int KH, int KW, int stride, int pad, int relu, void* y8, const float* q8, float* amax8,
+                                  void* stream) {
+  if (!y8) return CDDMSL_ERR_ARG;
+  return conv_fwd_impl(x, w, y, scale, bias, residual, relu_mask, Nimg, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 0, Cout, Cout, Cout,
+                       relu, 0, 0, y8, q8, amax8, stream);
+}
+
+// e4m3 x e4m3 -> bf16 (or f32) on the 256x256 kernel: x [Nimg][Hi][Wi][Cin] and w [Cout][KH][KW][Cin] hold OCP e4m3 bytes (Cin a
+// multiple of 128), everything else as cddmsl_conv_fwd with dtype 0: scale / bias f32 per output channel (the caller folds the two
+// per-tensor dequantisation factors into ``scale``), residual / relu_mask / y bf16 (y f32 with out_f32).  Only shapes the 256x256
+// kernel takes (Cout % 256 == 0, <= 31 taps, "same" padding at most); anything else is CDDMSL_ERR_ARG -- there is no fallback.
+extern "C" int cddmsl_conv_fwd_fp8(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                                   const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH,
+                                   int KW, int pad, int relu, int out_f32, void* y8, const float* q8, float* amax8, void* stream) {
+  if (Nimg < 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || (Cin % 128) != 0 || (out_f32 & ~1)) return CDDMSL_ERR_ARG;
+  ConvArgs a;
+  a.x = (const char*)x; a.w = (const char*)w; a.y = (char*)y; a.scale = scale; a.bias = bias;
+  a.residual = (const char*)residual; a.relu_mask = (const char*)relu_mask;
+  a.Nimg = Nimg; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad;
+  a.Ho = Hi + 2 * pad - KH + 1; a.Wo = Wi + 2 * pad - KW + 1;
+  if (a.Ho <= 0 || a.Wo <= 0) return CDDMSL_ERR_ARG;
+  a.ldy = a.ldr = a.ldm = Cout; a.relu = relu; a.out_f32 = out_f32; a.pool = 0; a.res_f32 = 0; a.res_pool = 0;
+  long M = (long)Nimg * a.Ho * a.Wo;
+  if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
+  a.M = (int)M; a.cpp = Cin / 16; a.Kc = KH * KW * a.cpp;
+  a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
+  a.dcpp = make_fastdiv((unsigned)a.cpp); a.dKW = make_fastdiv((unsigned)KW);
+  a.xrs = a.cpp; a.wrs = a.Kc; a.bx = a.bw = a.by = 0;
+  if (a.M == 0) return CDDMSL_OK;
+  if (!gemm256_legal(a)) return CDDMSL_ERR_ARG;
+  if (y8) {
+    if (out_f32) return CDDMSL_ERR_ARG;
+    a.y8 = (char*)y8; a.q8 = q8; a.amax8 = (unsigned*)amax8;
+  }
+  const long grid = (long)(a.Cout / 256) * ((a.M + 255) / 256);
+  if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  g_last_kernel = 10;
+  if (g_plan_only) return CDDMSL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (KH == 1 && KW == 1 && pad == 0) hipLaunchKernelGGL((k_conv_fwd256<fp8e4, false>), dim3((unsigned)grid, 1), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((k_conv_fwd256<fp8e4, true>), dim3((unsigned)grid, 1), dim3(512), 0, st, a);
+  return launch_status();
 }
 
 // The 256x256 wgrad kernel takes bf16 "same" problems with whole 256-wide output tiles and 8-chunk-aligned pixels

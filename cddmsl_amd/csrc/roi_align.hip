@@ -88,7 +88,11 @@ constexpr int ROI_MAXS = 256;     // samples per axis held in LDS (adaptive samp
 template <typename T, int RP>
 __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char* yp, int* dbg_grid, int N, int H, int W, int cch,
                                 int ph, int pw, float scale, int sampling_ratio, int aligned, const float* esc, const float* ebi,
-                                int relu) {
+                                int relu, char* y8, const float* q8, unsigned* amax8) {
+  // y8 (bf16 instantiation, fp8 configuration): a second, OCP e4m3 copy of y = sat(y * q8[0]) for the convolution that consumes
+  // the crops, max|y| recorded in amax8[block & 63] -- see cddmsl_conv_fwd_q8
+  const float q8s = (y8 && q8) ? q8[0] : 1.f;
+  float am8 = 0.f;
   const int nrb = ph / RP;
   const int i0 = (blockIdx.x % nrb) * RP, k = blockIdx.x / nrb;
   RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
@@ -193,6 +197,15 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char*
     }
     outp[rr][cc] = Vec<T>::pack(acc);
     if (y) ((u32x4*)y)[bin * cch + c] = outp[rr][cc];
+    if (sizeof(T) == 2 && y8) {
+      float f8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { am8 = fmaxf(am8, fabsf(acc[q])); f8[q] = __builtin_amdgcn_fmed3f(acc[q] * q8s, -448.f, 448.f); }
+      int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8[0], f8[1], 0, false), w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8[4], f8[5], 0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8[2], f8[3], w0, true); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8[6], f8[7], w1, true);
+      const u32x2 o8 = {(unsigned)w0, (unsigned)w1};
+      ((u32x2*)y8)[bin * cch + c] = o8;
+    }
     }
     if (RP == 2) {
       float a0[8], a1[8], a2[8], a3[8], o[8];
@@ -203,6 +216,17 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char*
       ((u32x4*)yp)[(((long)k * (ph / 2) + i0 / 2) * (pw / 2) + j0 / 2) * cch + c] = Vec<T>::pack(o);
     }
   }
+  }
+  if (sizeof(T) == 2 && y8 && amax8) {              // block-uniform condition
+    __shared__ float sm8[4];
+    am8 = wave_max(am8);
+    if ((threadIdx.x & 63) == 0) sm8[threadIdx.x >> 6] = am8;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = sm8[0];
+      for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) m = fmaxf(m, sm8[wv]);
+      atomicMax(amax8 + (blockIdx.x & 63), __float_as_uint(m));
+    }
   }
 }
 
@@ -354,20 +378,22 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(const char* dy, const flo
 
 static int roi_align_forward_impl(const void* x, const float* rois, void* y, void* y_pooled, int* dbg_grid, const float* esc,
                                   const float* ebi, int relu, int N, int C, int H, int W, int K, int ph, int pw, float spatial_scale,
-                                  int sampling_ratio, int aligned, int dtype, void* stream) {
+                                  int sampling_ratio, int aligned, int dtype, void* stream, void* y8 = nullptr, const float* q8 = nullptr,
+                                  float* amax8 = nullptr) {
   int es = dtype == 0 ? 2 : 4;
   if ((dtype != 0 && dtype != 1) || (C * es) % 16 || H <= 0 || W <= 0 || ph <= 0 || pw <= 0 || K < 0 || N < 0)
     return CDDMSL_ERR_ARG;
   if ((esc == nullptr) != (ebi == nullptr)) return CDDMSL_ERR_ARG;
   if (K == 0) return CDDMSL_OK;   // empty inputs return correctly-shaped empties (poolers.py:221-224)
   if (!y && !y_pooled) return CDDMSL_ERR_ARG;
+  if (y8 && (dtype != 0 || !y)) return CDDMSL_ERR_ARG;
   int cch = C * es / 16;
   if (y_pooled && ((ph & 1) || (pw & 1))) return CDDMSL_ERR_ARG;      // the pooled copy needs whole 2x2 groups of bins
   long grid = (long)K * (y_pooled ? ph / 2 : ph);
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   int threads = cch >= 256 ? 256 : ((cch + 63) / 64) * 64;
   hipStream_t st = (hipStream_t)stream;
-#define CDDMSL_RAF(TT, RPP) k_roi_align_fwd<TT, RPP><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, (char*)y_pooled, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned, esc, ebi, relu)
+#define CDDMSL_RAF(TT, RPP) k_roi_align_fwd<TT, RPP><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, (char*)y_pooled, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned, esc, ebi, relu, (char*)y8, q8, (unsigned*)amax8)
   if (dtype == 0) { if (y_pooled) CDDMSL_RAF(__bf16, 2); else CDDMSL_RAF(__bf16, 1); }
   else { if (y_pooled) CDDMSL_RAF(float, 2); else CDDMSL_RAF(float, 1); }
 #undef CDDMSL_RAF
@@ -388,9 +414,10 @@ extern "C" int cddmsl_roi_align_forward(const void* x, const float* rois, void* 
 // convolution over channels, so roi_align(x) W = roi_align(x W); the FrozenBN affine and the ReLU follow here.
 extern "C" int cddmsl_roi_align_forward_affine(const void* x, const float* rois, void* y, void* y_pooled, const float* scale,
                                                const float* bias, int relu, int N, int C, int H, int W, int K, int ph, int pw,
-                                               float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream) {
+                                               float spatial_scale, int sampling_ratio, int aligned, int dtype, void* y8,
+                                               const float* q8, float* amax8, void* stream) {
   return roi_align_forward_impl(x, rois, y, y_pooled, nullptr, scale, bias, relu, N, C, H, W, K, ph, pw, spatial_scale,
-                                sampling_ratio, aligned, dtype, stream);
+                                sampling_ratio, aligned, dtype, stream, y8, q8, amax8);
 }
 
 static int roi_align_backward_impl(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,

@@ -4,6 +4,7 @@ Every function here requires CUDA (=HIP) tensors and enqueues on torch's current
 fallbacks: a CPU tensor or a missing library raises ``HipLibraryError``.
 """
 import ctypes
+import os
 from ctypes import c_float, c_int, c_long, c_void_p
 
 import torch
@@ -45,7 +46,11 @@ def _L():
         L.cddmsl_sgd_clip_step.argtypes = [vp] * 4 + [ci, vp] + [cf] * 4 + [ci, vp]
         L.cddmsl_roi_align_forward.argtypes = [vp] * 5 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_roi_align_backward.argtypes = [vp] * 7 + [ci] * 7 + [cf, ci, ci, ci, vp]
-        L.cddmsl_roi_align_forward_affine.argtypes = [vp] * 6 + [ci] * 8 + [cf, ci, ci, ci, vp]
+        L.cddmsl_quantize_fp8.argtypes = [vp] * 4 + [c_long, ci, vp]
+        L.cddmsl_conv_fwd_fp8.argtypes = [vp] * 7 + [ci] * 10 + [vp] * 4
+        L.cddmsl_conv_fwd_q8.argtypes = [vp] * 7 + [ci] * 10 + [vp] * 4
+        L.cddmsl_fp8_dot_nt.argtypes = [vp] * 4 + [ci] * 4 + [vp]
+        L.cddmsl_roi_align_forward_affine.argtypes = [vp] * 6 + [ci] * 8 + [cf, ci, ci, ci] + [vp] * 4
         L.cddmsl_roi_align_backward_pooled.argtypes = [vp] * 7 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_anchors.argtypes = [vp, vp, ci, ci, ci, cf, cf, vp]
         L.cddmsl_sort_desc.argtypes = [vp] * 5 + [ci, ci, vp, vp, vp]
@@ -140,7 +145,7 @@ class _Profiler:
 
 PROFILE = _Profiler()
 # cddmsl_last_kernel() ids -> profiler row names (one row per KERNEL, so the roofline object describes one kernel)
-_CONV_KERNEL = {1: "k_conv_fwd", 2: "k_conv_fwd_reg", 3: "k_conv_fwd256", 4: "k_conv_wgrad", 5: "k_conv_wgrad_dma", 6: "k_wgrad256", 7: "k_gemm_tn_stream", 8: "k_conv3x3_small", 9: "k_gemm_tn_small"}
+_CONV_KERNEL = {10: "k_conv_fwd256_fp8", 1: "k_conv_fwd", 2: "k_conv_fwd_reg", 3: "k_conv_fwd256", 4: "k_conv_wgrad", 5: "k_conv_wgrad_dma", 6: "k_wgrad256", 7: "k_gemm_tn_stream", 8: "k_conv3x3_small", 9: "k_gemm_tn_small"}
 
 
 def _timed(name):
@@ -162,7 +167,7 @@ def _dt(t):
 
 
 def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=None, stride=1, pad=0,
-             pool=False, out_f32=False, residual_pooled=False):
+             pool=False, out_f32=False, residual_pooled=False, emit8=None):
     """x NHWC [N,H,W,Cin]; w [Cout,KH,KW,Cin] (same dtype).  Returns NHWC [N,Ho,Wo,Cout].
     y = relu?(acc*scale[n] + bias[n] + residual), zeroed where relu_mask <= 0 (ReLU backward).
     pool=True: 1x1 conv over the 2x2 average-pooled input (AvgPool2d(2) fused into the loader).
@@ -190,7 +195,15 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
     for v in (residual, relu_mask):
         assert v is None or (v is residual and residual_pooled) or (
             (v.dtype == x.dtype or (v is residual and res_f32)) and v.is_contiguous() and v.numel() == y.numel())
+    y8 = None
+    if emit8 is not None:     # fp8 configuration: (scale [1], amax [64]) of the consuming convolution's slot -> e4m3 copy of y, as y._fp8
+        assert x.dtype == torch.bfloat16 and not out_f32 and not pool and not residual_pooled and not res_f32
+        y8 = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
+
     def launch():
+        if y8 is not None:
+            return _L().cddmsl_conv_fwd_q8(ptr(x), ptr(w), ptr(y), ptr(scale), ptr(bias), ptr(residual), ptr(relu_mask),
+                                           N, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), ptr(y8), ptr(emit8[0]), ptr(emit8[1]), stream_ptr())
         return _L().cddmsl_conv_fwd(ptr(x), ptr(w), ptr(y), ptr(scale), ptr(bias), ptr(residual), ptr(relu_mask),
                                     N, H, W, Cin, Cout, KH, KW, stride, pad, int(pool), Cout, Cout, Cout,
                                     int(relu), int(out_f32) | (2 if res_f32 else 0) | (4 if residual_pooled else 0), _dt(x), stream_ptr())
@@ -204,7 +217,83 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
                 nbytes=float(x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()
                              + (residual.numel() * residual.element_size() if residual is not None else 0)
                              + (relu_mask.numel() * relu_mask.element_size() if relu_mask is not None else 0)))
+    if y8 is not None:
+        y._fp8 = (y8, emit8[0].data_ptr())
     return y
+
+
+def conv_emit8_ok(M, Cout, KH, KW, Cin_chunks_ok=True):
+    """can a bf16 launch carry the e4m3 second output? (the 256x256 kernel's epilogue writes it: whole 256-wide tiles, >= 160 tiles)"""
+    return Cout % 256 == 0 and KH * KW <= 31 and ((M + 255) // 256) * (Cout // 256) >= 160 and Cin_chunks_ok and os.environ.get("CDDMSL_GEMM256", "1") != "0"
+
+
+# ------------------------------------------------------------------------------------------------ e4m3 (fp8) configuration
+FP8_MAX = 448.0      # largest finite OCP e4m3fn magnitude
+
+
+@_timed("quantize_fp8")
+def quantize_fp8(x, scale=None, amax=None):
+    """x (bf16 or f32, contiguous, numel % 8 == 0) -> uint8 tensor of OCP e4m3 bytes = sat(x * scale[0]).  ``scale`` / ``amax``:
+    1-element f32 device tensors; max|x| is atomically max-ed into ``amax`` (delayed scaling: next step's scale)."""
+    require_cuda(x, scale, amax)
+    assert x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32) and x.numel() % 8 == 0
+    y = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    check(_L().cddmsl_quantize_fp8(ptr(x), ptr(y), ptr(scale), ptr(amax), x.numel(), 0 if x.dtype == torch.bfloat16 else 1, stream_ptr()),
+          "cddmsl_quantize_fp8")
+    return y
+
+
+def conv_fwd_fp8_ok(M, Cin, Cout, KH, KW, pad):
+    """shapes the e4m3 kernel takes AND wins on: whole 256-wide tiles, enough of them to fill the chip, a reduction long enough to
+    be MFMA-bound in bf16 (short reductions are bound by their output traffic, which fp8 operands do not shrink)"""
+    min_tiles = int(os.environ.get("CDDMSL_FP8_MIN_TILES", "160"))      # (tests lower both to reach the kernel at small sizes)
+    min_k = int(os.environ.get("CDDMSL_FP8_MIN_K", "2048"))
+    return Cin % 128 == 0 and Cout % 256 == 0 and KH * KW <= 31 and 2 * pad <= KH - 1 and ((M + 255) // 256) * (Cout // 256) >= min_tiles \
+        and KH * KW * Cin >= min_k
+
+
+def conv_fwd_fp8(x8, w8, scale=None, bias=None, residual=None, relu=False, relu_mask=None, pad=0, out_f32=False, emit8=None):
+    """x8 uint8 (e4m3) NHWC [N,H,W,Cin]; w8 uint8 [Cout,KH,KW,Cin].  y (bf16, or f32) = epilogue(sum x8 * w8): ``scale`` must carry
+    the two dequantisation factors (x the FrozenBN scale).  stride 1."""
+    require_cuda(x8, w8, scale, bias, residual, relu_mask)
+    assert x8.dtype == torch.uint8 and w8.dtype == torch.uint8 and x8.is_contiguous() and w8.is_contiguous()
+    N, H, W, Cin = x8.shape
+    Cout, KH, KW, Cin2 = w8.shape
+    assert Cin == Cin2
+    Ho, Wo = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
+    y = torch.empty((N, Ho, Wo, Cout), device=x8.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    for v in (scale, bias):
+        assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
+    for v in (residual, relu_mask):
+        assert v is None or (v.dtype == torch.bfloat16 and v.is_contiguous() and v.numel() == y.numel())
+
+    y8 = torch.empty(y.shape, device=x8.device, dtype=torch.uint8) if emit8 is not None else None
+    assert emit8 is None or not out_f32
+
+    def launch():
+        return _L().cddmsl_conv_fwd_fp8(ptr(x8), ptr(w8), ptr(y), ptr(scale), ptr(bias), ptr(residual), ptr(relu_mask),
+                                        N, H, W, Cin, Cout, KH, KW, pad, int(relu), int(out_f32), ptr(y8),
+                                        ptr(emit8[0]) if emit8 else c_void_p(0), ptr(emit8[1]) if emit8 else c_void_p(0), stream_ptr())
+    e0 = PROFILE.begin(name="k_conv_fwd256_fp8") if PROFILE.on else None
+    check(launch(), "cddmsl_conv_fwd_fp8")
+    PROFILE.end(e0, "k_conv_fwd256_fp8", 2.0 * N * Ho * Wo * Cout * KH * KW * Cin, (N * Ho * Wo, Cout, KH * KW * Cin, KH, 0, 1),
+                nbytes=float(x8.numel() + w8.numel() + y.numel() * y.element_size() + (residual.numel() * 2 if residual is not None else 0)
+                             + (relu_mask.numel() * 2 if relu_mask is not None else 0)))
+    if y8 is not None:
+        y._fp8 = (y8, emit8[0].data_ptr())
+    return y
+
+
+@_timed("fp8_dot_nt")
+def fp8_dot_nt(a8, b8, alpha=None):
+    """a8 [R,K], b8 [N,K] uint8 (e4m3), N <= 32, K % 64 == 0 -> [R,N] f32 = alpha[0] * a . b^T"""
+    require_cuda(a8, b8, alpha)
+    R, K = a8.shape
+    N = b8.shape[0]
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.is_contiguous() and b8.is_contiguous() and b8.shape[1] == K
+    c = torch.empty((R, N), device=a8.device, dtype=torch.float32)
+    check(_L().cddmsl_fp8_dot_nt(ptr(a8), ptr(b8), ptr(c), ptr(alpha), R, N, K, N, stream_ptr()), "cddmsl_fp8_dot_nt")
+    return c
 
 
 def pooled_residual_ok(t):
@@ -474,7 +563,7 @@ def roi_align_forward(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, d
 
 @_timed("roi_align_forward")
 def roi_align_forward_affine(x, rois, ph, pw, spatial_scale, sampling_ratio, aligned, scale=None, bias=None, relu=False,
-                             pooled_only=False, extra_rows=0):
+                             pooled_only=False, extra_rows=0, emit8=None):
     """RoIAlign of a map that already went through a 1x1 convolution (layers.RoIStageFn):
     ``pooled_only=False``: y [K,ph,pw,C] = relu?(scale * roi_align(x) + bias) (per channel, f32 scale / bias);
     ``pooled_only=True``: only AvgPool2d(2) of the crops, [K,ph/2,pw/2,C] (no affine) -- the full-resolution crops are never written."""
@@ -488,9 +577,16 @@ def roi_align_forward_affine(x, rois, ph, pw, spatial_scale, sampling_ratio, ali
     else:
         y, yp = torch.empty((K + extra_rows, ph, pw, C), device=x.device, dtype=x.dtype), None
         assert scale is None or (scale.dtype == torch.float32 and scale.numel() == C and bias.numel() == C and scale.is_contiguous() and bias.is_contiguous())
+    y8 = None
+    if emit8 is not None:     # e4m3 copy of the crops for the convolution that consumes them (fp8 configuration), as y._fp8
+        assert not pooled_only and x.dtype == torch.bfloat16
+        y8 = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
     check(_L().cddmsl_roi_align_forward_affine(ptr(x), ptr(rois), ptr(y), ptr(yp), ptr(scale), ptr(bias), int(relu), N, C, H, W, K,
-                                                ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(x), stream_ptr()),
+                                                ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(x), ptr(y8),
+                                                ptr(emit8[0]) if emit8 else c_void_p(0), ptr(emit8[1]) if emit8 else c_void_p(0), stream_ptr()),
           "cddmsl_roi_align_forward_affine")
+    if y8 is not None:
+        y._fp8 = (y8, emit8[0].data_ptr())
     return yp if pooled_only else y
 
 

@@ -121,6 +121,113 @@ class PreparedWeight:
         return self._wf, self._wd
 
 
+# ------------------------------------------------------------------------------------------------
+# OCP e4m3 (fp8) forward GEMMs -- BASELINE.json configs[4]; no counterpart in the reference (AMP off, config/defaults.py:697)
+# ------------------------------------------------------------------------------------------------
+class Fp8Scales:
+    """Per-tensor delayed scaling, entirely on the device: slot = (scale, 1/scale, 64 words of running max|x|).  A quantising
+    launch (the quantise kernel, or the epilogue of the convolution / RoIAlign launch that produces the tensor) reads its slot's
+    scale and max-es the tensor's magnitude into the slot's words (atomics spread by block); ``roll()`` (once per optimizer
+    step) turns the recorded maxima into the next step's scales.  No host round trip anywhere; first use runs with scale 1."""
+
+    CAP, W = 512, 66
+
+    def __init__(self):
+        self.buf, self.used = None, 0
+
+    def slot(self, device):
+        if self.buf is None or self.buf.device != torch.device(device):
+            self.buf = torch.zeros(self.CAP, self.W, device=device, dtype=torch.float32)
+            self.buf[:, :2] = 1.0
+            self.used = 0
+        assert self.used < self.CAP
+        row = self.buf[self.used]
+        self.used += 1
+        return row[0:1], row[1:2], row[2:]            # scale [1], dequantisation factor [1], amax words [64]
+
+    def roll(self, margin=1.0):
+        if self.buf is None or self.used == 0:
+            return
+        b = self.buf[: self.used]
+        amax = b[:, 2:].amax(dim=1)
+        new = torch.where(amax > 0, (hip.FP8_MAX * margin) / amax.clamp_min(1e-30), b[:, 0])
+        b[:, 0] = new
+        b[:, 1] = 1.0 / new
+        b[:, 2:] = 0.0
+
+
+FP8_SCALES = Fp8Scales()
+
+
+def fp8_weight(pw):
+    """PreparedWeight -> (e4m3 forward weights [Cout,KH,KW,Cin] uint8, dequantisation factor [1] f32), per-tensor scale from the
+    weight's own current maximum; cached like the bf16 copies (refreshed after every optimizer step / load)."""
+    key = (-1 if pw.frozen else _STEP[0], pw.param.data_ptr(), pw.param._version, _LOAD_GEN[0])
+    c = getattr(pw, "_fp8", None)
+    if c is None or c[0] != key:
+        w = _ohwi(pw.param.detach()).contiguous()
+        amax = w.abs().amax().clamp_min(1e-20).view(1)
+        w8 = hip.quantize_fp8(w, hip.FP8_MAX / amax)
+        pw._fp8 = c = (key, w8, amax / hip.FP8_MAX)
+    return c[1], c[2]
+
+
+def fp8_act_slot(pw):
+    """the delayed-scaling slot of the activation tensor that feeds this weight's convolution"""
+    sl = getattr(pw, "_fp8_slot", None)
+    if sl is None or sl[0].device != pw.param.device:
+        pw._fp8_slot = sl = FP8_SCALES.slot(pw.param.device)
+    return sl
+
+
+def _fp8_eligible(pw, in_shape, pad=0):
+    Cout, KH, KW, Cin = _ohwi(pw.param).shape
+    N, H, W, _ = in_shape
+    M = N * (H + 2 * pad - KH + 1) * (W + 2 * pad - KW + 1)
+    return hip.conv_fwd_fp8_ok(M, Cin, Cout, KH, KW, pad)
+
+
+def fp8_emit_for(consumer_pw, out_shape, pad, fp8, producer_cout=None, producer_taps=1):
+    """(scale, amax) of the slot of the convolution that will read a tensor of ``out_shape`` through ``consumer_pw`` -- handed to
+    the PRODUCING launch so that its epilogue writes the e4m3 copy -- or None (consumer not on the e4m3 kernel, or the producer's
+    launch cannot carry a second output)."""
+    if not fp8 or consumer_pw is None or not _fp8_eligible(consumer_pw, out_shape, pad):
+        return None
+    M = out_shape[0] * out_shape[1] * out_shape[2]
+    if producer_cout is not None and not hip.conv_emit8_ok(M, producer_cout, producer_taps, 1):
+        return None
+    s_x, _, amax = fp8_act_slot(consumer_pw)
+    return (s_x, amax)
+
+
+def conv_fwd_auto(x, pw, scale=None, bias=None, fp8=False, emit8=None, **kw):
+    """``hip.conv_fwd`` on the prepared bf16 / f32 weights, or -- with ``fp8`` on shapes the e4m3 kernel takes and wins on
+    (``hip.conv_fwd_fp8_ok``: MFMA-bound in bf16) -- the e4m3 kernel on the input's e4m3 copy: the one its producer wrote
+    (``x._fp8``, made with this convolution's slot) or, failing that, one quantisation pass; both dequantisation factors ride in
+    the epilogue's per-channel scale.  ``emit8``: (scale, amax) for an e4m3 copy of the OUTPUT (``fp8_emit_for``).
+    kw: residual, relu, relu_mask, pad."""
+    T = x.dtype
+    if fp8 and T == torch.bfloat16 and kw.get("stride", 1) == 1 and not kw.get("out_f32", False):
+        Cout = _ohwi(pw.param).shape[0]
+        pad = kw.get("pad", 0)
+        if _fp8_eligible(pw, x.shape, pad):
+            s_x, d_x, amax = fp8_act_slot(pw)
+            made = getattr(x, "_fp8", None)
+            x8 = made[0] if made is not None and made[1] == s_x.data_ptr() else hip.quantize_fp8(x, s_x, amax)
+            w8, d_w = fp8_weight(pw)
+            eff = (d_x * d_w) * scale if scale is not None else (d_x * d_w).expand(Cout).contiguous()
+            return hip.conv_fwd_fp8(x8, w8, eff, bias, kw.get("residual"), kw.get("relu", False), kw.get("relu_mask"), pad, emit8=emit8)
+    wf, _ = pw.get(T, need_dgrad=False)
+    if emit8 is not None:
+        Cout, KH, KW, Cin = _ohwi(pw.param).shape
+        N, H, W, _ = x.shape
+        pad = kw.get("pad", 0)
+        M = N * (H + 2 * pad - KH + 1) * (W + 2 * pad - KW + 1)
+        if not (T == torch.bfloat16 and hip.conv_emit8_ok(M, Cout, KH, KW, (Cin * 2 // 16) % 8 == 0) and kw.get("stride", 1) == 1):
+            emit8 = None
+    return hip.conv_fwd(x, wf, scale, bias, emit8=emit8, **kw)
+
+
 def cat_prepared(weights, dtype):
     """Concatenate several [Ni,K] / 1x1 weights into one [sum Ni,1,1,K] GEMM operand (fused heads)."""
     return torch.cat([hip.weight_prep(_ohwi(w.detach()), None, dtype, True, False)[0] for w in weights], dim=0)
@@ -134,10 +241,9 @@ class ConvFn(torch.autograd.Function):
     weights (input gradient only)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, pw, bias, stride, pad, relu, out_f32, train_w, residual=None):
-        wf, _ = pw.get(x.dtype, need_dgrad=False)
-        y = hip.conv_fwd(x, wf, None, None if bias is None else bias.detach(), None if residual is None else residual.detach(),
-                         relu=relu, stride=stride, pad=pad, out_f32=out_f32)
+    def forward(ctx, x, anchor, pw, bias, stride, pad, relu, out_f32, train_w, residual=None, fp8=False):
+        y = conv_fwd_auto(x, pw, None, None if bias is None else bias.detach(), fp8, residual=None if residual is None else residual.detach(),
+                          relu=relu, stride=stride, pad=pad, out_f32=out_f32)
         ctx.pw, ctx.bias, ctx.cfg = pw, bias, (stride, pad, relu, out_f32, train_w)
         ctx.save_for_backward(x, y if relu else None)
         return y
@@ -174,7 +280,7 @@ class ConvFn(torch.autograd.Function):
             else:
                 dx = hip.conv_fwd(dy, wd, stride=1, pad=KH - 1 - pad)
         # y = conv + residual (no ReLU with a residual): the residual's gradient is the incoming one, as it came
-        return dx, None, None, None, None, None, None, None, None, (dy_in if ctx.needs_input_grad[9] else None)
+        return dx, None, None, None, None, None, None, None, None, (dy_in if ctx.needs_input_grad[9] else None), None
 
 
 class FrozenMlpFn(torch.autograd.Function):
@@ -213,11 +319,12 @@ def frozen_mlp(x2d, pw1, b1, pw2, b2, residual):
     return FrozenMlpFn.apply(x2d.contiguous(), pw1, b1, pw2, b2, residual.contiguous())
 
 
-def conv(x, pw, bias=None, stride=1, pad=0, relu=False, out_f32=False, train_w=True, residual=None):
-    """``residual`` (same shape as the output; f32 with ``out_f32`` on the bf16 path) is added in the GEMM epilogue."""
+def conv(x, pw, bias=None, stride=1, pad=0, relu=False, out_f32=False, train_w=True, residual=None, fp8=False):
+    """``residual`` (same shape as the output; f32 with ``out_f32`` on the bf16 path) is added in the GEMM epilogue.
+    ``fp8``: forward on e4m3 operands where the shape qualifies (``conv_fwd_auto``); backward unchanged (bf16)."""
     anchor = pw.param if train_w else None
     assert residual is None or not relu
-    return ConvFn.apply(x, anchor, pw, bias, stride, pad, relu, out_f32, train_w, residual)
+    return ConvFn.apply(x, anchor, pw, bias, stride, pad, relu, out_f32, train_w, residual, fp8)
 
 
 def linear(x2d, pw, bias=None, relu=False, out_f32=False, train_w=True, residual=None):
@@ -280,35 +387,34 @@ def fused_heads(x, heads, out_f32=True):
 class BlockParams:
     """Weights + folded FrozenBN affine of one Bottleneck (clip_backbone.py:14-70)."""
 
-    def __init__(self, w1, w2, w3, wd, bn1, bn2, bn3, bnd, stride, frozen):
-        self.stride, self.frozen = stride, frozen
+    def __init__(self, w1, w2, w3, wd, bn1, bn2, bn3, bnd, stride, frozen, fp8=False):
+        self.stride, self.frozen, self.fp8 = stride, frozen, fp8
         self.bn = (bn1, bn2, bn3, bnd)  # each = (scale, bias) f32
         self.w = (w1, w2, w3, wd)
         self.pw = tuple(None if w is None else PreparedWeight(w, b[0], frozen) for w, b in zip(self.w, self.bn))
 
 
-def _block_forward(x, bp, save, px_given=None):
+def _block_forward(x, bp, save, px_given=None, next_pw=None):
+    # (next_pw: conv1 of the block that reads this block's output -- fp8 configuration: its e4m3 copy is written here)
     """Bottleneck forward (clip_backbone.py:57-70).  AvgPool2d(stride) runs as its own HBM-bound kernel: fusing it into
     the GEMM A-loader (kernel option pool=1, kept and tested) halves the MFMA rate of this kernel structure."""
-    T = x.dtype
     (s1, b1), (s2, b2), (s3, b3), bnd = bp.bn
-    w1, _ = bp.pw[0].get(T, False)
-    w2, _ = bp.pw[1].get(T, False)
-    w3, _ = bp.pw[2].get(T, False)
     pool = bp.stride > 1
-    o1 = hip.conv_fwd(x, w1, s1, b1, relu=True)
-    o2 = hip.conv_fwd(o1, w2, s2, b2, relu=True, pad=1)
+    f8 = bp.fp8
+    o1_shape = (x.shape[0], x.shape[1], x.shape[2], _ohwi(bp.w[0]).shape[0])
+    o1 = conv_fwd_auto(x, bp.pw[0], s1, b1, f8, emit8=fp8_emit_for(bp.pw[1], o1_shape, 1, f8), relu=True)     # (conv2 reads o1's e4m3 copy)
+    o2 = conv_fwd_auto(o1, bp.pw[1], s2, b2, f8, relu=True, pad=1)
     p2 = hip.avgpool2_fwd(o2) if pool else o2
     if pool and px_given is not None and tuple(px_given.shape) == (x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]):
         px = px_given                              # the producer of x pooled it on the way (roi_align with_pooled)
     else:
         px = hip.avgpool2_fwd(x) if pool else x
     if bp.pw[3] is not None:
-        wd, _ = bp.pw[3].get(T, False)
-        idn = hip.conv_fwd(px, wd, bnd[0], bnd[1])
+        idn = conv_fwd_auto(px, bp.pw[3], bnd[0], bnd[1], f8)
     else:
         idn = x
-    out = hip.conv_fwd(p2, w3, s3, b3, residual=idn, relu=True)
+    out_shape = (p2.shape[0], p2.shape[1], p2.shape[2], _ohwi(bp.w[2]).shape[0])
+    out = conv_fwd_auto(p2, bp.pw[2], s3, b3, f8, emit8=fp8_emit_for(next_pw, out_shape, 0, f8), residual=idn, relu=True)
     return out, ((o1, o2, p2 if pool else None, px if pool else None) if save else None)
 
 
@@ -358,7 +464,7 @@ class ResStageFn(torch.autograd.Function):
         saved = [x]
         cur = x
         for bi, bp in enumerate(blocks):
-            cur, mids = _block_forward(cur, bp, True, px0 if bi == 0 else None)
+            cur, mids = _block_forward(cur, bp, True, px0 if bi == 0 else None, blocks[bi + 1].pw[0] if bi + 1 < len(blocks) else None)
             saved += [mids[0], mids[1], mids[2], mids[3], cur]
         ctx.blocks = blocks
         ctx.save_for_backward(*saved)
@@ -383,7 +489,7 @@ def res_stage(x, blocks, frozen, out_grad_premasked=False):
     if frozen or not torch.is_grad_enabled():
         cur = x
         for bi, bp in enumerate(blocks):
-            cur, _ = _block_forward(cur, bp, False, px0 if bi == 0 else None)
+            cur, _ = _block_forward(cur, bp, False, px0 if bi == 0 else None, blocks[bi + 1].pw[0] if bi + 1 < len(blocks) else None)
         return cur
     return ResStageFn.apply(x, blocks[0].w[0], blocks, out_grad_premasked, px0)
 
@@ -400,7 +506,7 @@ def res_stage_attnpool(x, blocks, frozen, ap):
 # ------------------------------------------------------------------------------------------------
 # RoIAlign -> CLIP layer4 with the first block's conv1 moved in front of the pooling
 # ------------------------------------------------------------------------------------------------
-def _roi_block0_forward(feat, rois, bp, out_size, scale, sr, extra):
+def _roi_block0_forward(feat, rois, bp, out_size, scale, sr, extra, next_pw=None):
     """First Bottleneck of the RoI head's layer4 (clip_roi_heads.py:113-115 -> clip_backbone.py:57-70) on the pooled crops, WITHOUT
     the crops: RoIAlign is a linear map over pixels and conv1 / the downsample conv are 1x1 (linear over channels), so
 
@@ -412,20 +518,21 @@ def _roi_block0_forward(feat, rois, bp, out_size, scale, sr, extra):
     T = feat.dtype
     (s1, b1), (s2, b2), (s3, b3), bnd = bp.bn
     w1, _ = bp.pw[0].get(T, False)
-    w2, _ = bp.pw[1].get(T, False)
-    w3, _ = bp.pw[2].get(T, False)
-    wd, _ = bp.pw[3].get(T, False)
+    f8 = bp.fp8
     K, E = rois.shape[0], (0 if extra is None else extra.shape[0])
     z = hip.conv_fwd(feat, w1)                                                              # conv1 on the feature map, no affine yet
-    o1 = hip.roi_align_forward_affine(z, rois, out_size, out_size, scale, sr, True, s1, b1, relu=True, extra_rows=E)
+    o1_shape = (K + E, out_size, out_size, z.shape[-1])
+    e8 = fp8_emit_for(bp.pw[1], o1_shape, 1, f8) if E == 0 else None                       # (appended maps are copied in afterwards: quantise then)
+    o1 = hip.roi_align_forward_affine(z, rois, out_size, out_size, scale, sr, True, s1, b1, relu=True, extra_rows=E, emit8=e8)
     px = hip.roi_align_forward_affine(feat, rois, out_size, out_size, scale, sr, True, pooled_only=True, extra_rows=E)
     if E:                                            # maps of the crops' geometry riding behind them (the 224x224 crops' res4)
         o1[K:].copy_(hip.conv_fwd(extra, w1, s1, b1, relu=True))
         px[K:].copy_(hip.avgpool2_fwd(extra))
-    o2 = hip.conv_fwd(o1, w2, s2, b2, relu=True, pad=1)
+    o2 = conv_fwd_auto(o1, bp.pw[1], s2, b2, f8, relu=True, pad=1)
     p2 = hip.avgpool2_fwd(o2)
-    idn = hip.conv_fwd(px, wd, bnd[0], bnd[1])
-    out = hip.conv_fwd(p2, w3, s3, b3, residual=idn, relu=True)
+    idn = conv_fwd_auto(px, bp.pw[3], bnd[0], bnd[1], f8)
+    out_shape = (p2.shape[0], p2.shape[1], p2.shape[2], _ohwi(bp.w[2]).shape[0])
+    out = conv_fwd_auto(p2, bp.pw[2], s3, b3, f8, emit8=fp8_emit_for(next_pw, out_shape, 0, f8), residual=idn, relu=True)
     return o1, o2, p2, px, out
 
 
@@ -438,10 +545,11 @@ class RoIStageFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, anchor, rois, roi_start, blocks, out_size, scale, sr, out_grad_premasked, extra):
         feat = feat.contiguous()
-        o1, o2, p2, px, cur = _roi_block0_forward(feat, rois, blocks[0], out_size, scale, sr, extra)
+        nxt = lambda i: blocks[i + 1].pw[0] if i + 1 < len(blocks) else None
+        o1, o2, p2, px, cur = _roi_block0_forward(feat, rois, blocks[0], out_size, scale, sr, extra, nxt(0))
         saved = [feat, rois, roi_start, extra, o1, o2, p2, px, cur]
-        for bp in blocks[1:]:
-            cur, mids = _block_forward(cur, bp, True)
+        for bi, bp in enumerate(blocks[1:], start=1):
+            cur, mids = _block_forward(cur, bp, True, None, nxt(bi))
             saved += [mids[0], mids[1], mids[2], mids[3], cur]
         ctx.blocks, ctx.meta = blocks, (out_size, scale, sr, out_grad_premasked)
         ctx.save_for_backward(*saved)
@@ -501,9 +609,10 @@ def roi_stage(feat, rois, roi_start, blocks, frozen, out_size, scale, sr, extra=
     assert rois.dim() == 2 and rois.size(1) == 5 and out_size % 2 == 0                     # layers/roi_align.py:55
     assert extra is None or tuple(extra.shape[1:]) == (out_size, out_size, feat.shape[3])
     if frozen or not torch.is_grad_enabled():
-        cur = _roi_block0_forward(feat.contiguous(), rois, blocks[0], out_size, scale, sr, extra)[4]
-        for bp in blocks[1:]:
-            cur, _ = _block_forward(cur, bp, False)
+        nxt = lambda i: blocks[i + 1].pw[0] if i + 1 < len(blocks) else None
+        cur = _roi_block0_forward(feat.contiguous(), rois, blocks[0], out_size, scale, sr, extra, nxt(0))[4]
+        for bi, bp in enumerate(blocks[1:], start=1):
+            cur, _ = _block_forward(cur, bp, False, None, nxt(bi))
         return cur
     return RoIStageFn.apply(feat, blocks[0].w[0], rois, roi_start, blocks, out_size, scale, sr, out_grad_premasked, extra)
 
@@ -684,10 +793,34 @@ def attnpool(x, ap):
 # ------------------------------------------------------------------------------------------------
 # fp32 heads: cosine-logit classifier (fast_rcnn.py:546-572) and contrastive loss (rcnn.py:308-317)
 # ------------------------------------------------------------------------------------------------
+_FP8_CONST = {}
+
+
+def _fp8_const(value, device):
+    k = (float(value), str(device))
+    if k not in _FP8_CONST:
+        _FP8_CONST[k] = torch.tensor([float(value)], device=device, dtype=torch.float32)
+    return _FP8_CONST[k]
+
+
 class CosineLogitsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wn, temperature):
-        scores, inv = hip.cosine_logits_fwd(x.contiguous(), wn, temperature)
+    def forward(ctx, x, wn, temperature, fp8=False):
+        x = x.contiguous()
+        if fp8 and x.shape[1] % 64 == 0 and wn.shape[0] <= 32:
+            # the region x text-embedding contraction on e4m3 operands (BASELINE.json configs[4]): rows are unit vectors, so a fixed
+            # scale of 448 uses the format's whole range; f32 accumulation, 1 / (448^2 T) applied to the f32 result.  The
+            # backward is the exact-f32 one (straight-through: the quantisation is not differentiated).
+            xn, inv = hip.l2norm_fwd(x, 1e-12)
+            unit = _fp8_const(hip.FP8_MAX, x.device)
+            key = (wn.data_ptr(), wn._version)
+            c = _FP8_CONST.get("wn")
+            if c is None or c[0] != key:
+                _FP8_CONST["wn"] = c = (key, hip.quantize_fp8(wn.contiguous(), unit))
+            dot = hip.fp8_dot_nt(hip.quantize_fp8(xn, unit), c[1], _fp8_const(1.0 / (hip.FP8_MAX * hip.FP8_MAX * temperature), x.device))
+            scores = torch.cat([dot, torch.zeros(x.shape[0], 1, device=x.device, dtype=torch.float32)], dim=1)
+        else:
+            scores, inv = hip.cosine_logits_fwd(x, wn, temperature)
         ctx.save_for_backward(x, wn, inv)
         ctx.t = temperature
         return scores
@@ -695,11 +828,11 @@ class CosineLogitsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ds):
         x, wn, inv = ctx.saved_tensors
-        return hip.cosine_logits_bwd(ds, x.contiguous(), wn, inv, ctx.t), None, None
+        return hip.cosine_logits_bwd(ds, x.contiguous(), wn, inv, ctx.t), None, None, None
 
 
-def cosine_logits(x, wn, temperature):
-    return CosineLogitsFn.apply(x, wn, temperature)
+def cosine_logits(x, wn, temperature, fp8=False):
+    return CosineLogitsFn.apply(x, wn, temperature, fp8)
 
 
 class ContrastiveFn(torch.autograd.Function):

@@ -82,7 +82,7 @@ class Bottleneck(nn.Module):
         return layers.BlockParams(self.conv1.weight, self.conv2.weight, self.conv3.weight,
                                   None if ds is None else ds[0].weight,
                                   self.bn1.affine(), self.bn2.affine(), self.bn3.affine(),
-                                  None if ds is None else ds[1].affine(), self.stride, self.frozen)
+                                  None if ds is None else ds[1].affine(), self.stride, self.frozen, getattr(self, "fp8", False))
 
 
 class ResStage(nn.Sequential):
@@ -238,9 +238,15 @@ def build_clip_resnet_backbone(cfg, input_shape=None):
     width = {50: 64, 101: 64, 200: 80}[depth]
     embed_dim = {50: 1024, 101: 512, 200: 640}[depth]
     res = {50: 224, 101: 224, 200: 288}[depth]
-    dt = {"bf16": torch.bfloat16, "f32": torch.float32}[cfg.MODEL.get("COMPUTE_DTYPE", "bf16")]
-    return ModifiedResNet(blocks, embed_dim, width * 32 // 64, res, width, cfg.MODEL.RESNETS.OUT_FEATURES,
-                          cfg.MODEL.BACKBONE.FREEZE_AT, depth, False, True, dt)
+    mode = cfg.MODEL.get("COMPUTE_DTYPE", "bf16")
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": torch.bfloat16}[mode]
+    net = ModifiedResNet(blocks, embed_dim, width * 32 // 64, res, width, cfg.MODEL.RESNETS.OUT_FEATURES,
+                         cfg.MODEL.BACKBONE.FREEZE_AT, depth, False, True, dt)
+    if mode == "fp8":      # BASELINE.json configs[4]: e4m3 forward GEMMs where they are MFMA-bound (layers.conv_fwd_auto), rest bf16
+        for m in net.modules():
+            if isinstance(m, Bottleneck):
+                m.fp8 = True
+    return net
 
 
 def build_backbone(cfg, input_shape=None):

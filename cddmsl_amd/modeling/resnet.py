@@ -212,5 +212,5 @@ def build_resnet_backbone(cfg, input_shape=None):
         first = 1 if idx == 0 else 2
         stages.append(make_stage(nblocks[idx], [first] + [1] * (nblocks[idx] - 1), inc, bott, outc))
         inc, outc, bott = outc, outc * 2, bott * 2
-    dt = {"bf16": torch.bfloat16, "f32": torch.float32}[cfg.MODEL.get("COMPUTE_DTYPE", "bf16")]
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": torch.bfloat16}[cfg.MODEL.get("COMPUTE_DTYPE", "bf16")]   # (stock ResNet: fp8 = bf16)
     return ResNet(BasicStem(3, r.STEM_OUT_CHANNELS), stages, out_features, cfg.MODEL.BACKBONE.FREEZE_AT, dt)

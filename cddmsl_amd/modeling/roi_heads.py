@@ -165,7 +165,8 @@ class FastRCNNOutputLayers(nn.Module):
         self.no_box_delta = bool(c.NO_BOX_DELTA)
         self.multiply_rpn_score = bool(c.MULTIPLY_RPN_SCORE)
         assert not cfg.MODEL.ROI_HEADS.get("SOFT_NMS_ENABLED", False), "soft-NMS is off the hot path (defaults.py:399)"
-        self.compute_dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[cfg.MODEL.get("COMPUTE_DTYPE", "bf16")]
+        self.compute_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": torch.bfloat16}[cfg.MODEL.get("COMPUTE_DTYPE", "bf16")]
+        self.fp8 = cfg.MODEL.get("COMPUTE_DTYPE", "bf16") == "fp8"
         self._wn = None
         self.storage = {}
 
@@ -180,7 +181,7 @@ class FastRCNNOutputLayers(nn.Module):
         """x [R, 1024] f32 -> (scores [R, K+1] f32, deltas [R, 4K] f32)   fast_rcnn.py:529-572"""
         xt = x.to(self.compute_dtype)
         if self.use_clip_cls_emb:
-            scores = layers.cosine_logits(x, self._text_emb(), self.temperature)
+            scores = layers.cosine_logits(x, self._text_emb(), self.temperature, fp8=self.fp8)
             deltas = layers.linear(xt, self.bbox_pred.pw(), self.bbox_pred.bias, out_f32=True)
             return scores, deltas
         # plain classifier: cls_score (K+1) and bbox_pred (4K) as ONE padded GEMM (row widths must be whole 16-B chunks)

@@ -185,12 +185,13 @@ class StandardRPNHead(nn.Module):
             in_channels = input_shape[0].channels
             num_anchors = build_anchor_generator(cfg, input_shape).num_anchors[0]
             assert list(cfg.MODEL.RPN.CONV_DIMS) == [-1]
+        self.fp8 = cfg is not None and cfg.MODEL.get("COMPUTE_DTYPE", "bf16") == "fp8"
         self.conv = _Conv2d(in_channels, in_channels, 3)
         self.objectness_logits = _Conv2d(in_channels, num_anchors, 1)
         self.anchor_deltas = _Conv2d(in_channels, num_anchors * box_dim, 1)
 
     def forward_nhwc(self, x):
-        t = layers.conv(x, self.conv.pw(), self.conv.bias, 1, 1, relu=True)
+        t = layers.conv(x, self.conv.pw(), self.conv.bias, 1, 1, relu=True, fp8=self.fp8)
         a = self.objectness_logits.weight.shape[0]
         y = layers.fused_heads(t, [(self.objectness_logits.weight, self.objectness_logits.bias),
                                    (self.anchor_deltas.weight, self.anchor_deltas.bias)])      # one GEMM, N = 5A (padded)

@@ -67,6 +67,7 @@ class ClippedSGD:
         self.steps_done += 1
         self.iteration += 1
         layers.bump_weight_version()   # prepared (cast / transposed) weights are stale now
+        layers.FP8_SCALES.roll()       # fp8 configuration: this step's recorded activation maxima become the next step's scales
         return lr
 
 

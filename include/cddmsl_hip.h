@@ -65,6 +65,30 @@ int cddmsl_weight_prep(const float* w, const float* scale, void* w_fwd, void* w_
  * Cout, KH, KW, Cin}.  Used once per step after the optimizer update. */
 int cddmsl_weight_prep_multi(const long long* table, int count, int dtype, void* stream);
 
+/* ---- OCP e4m3 (fp8) configuration: BASELINE.json configs[4] ------------------------------------------------------------------
+ * The reference has no fp8 path (AMP is off, config/defaults.py:697): these entry points have no counterpart there; they replace,
+ * for the MFMA-bound forward convolutions of layer3 / layer4 / the RoI head's layer4 (clip_backbone.py:57-70) and for the region x
+ * text-embedding contraction (roi_heads/fast_rcnn.py:546-572), the bf16 launches of cddmsl_conv_fwd / cddmsl_cosine_logits_fwd.
+ *   cddmsl_quantize_fp8   x (src_dtype 0 bf16 / 1 f32, numel % 8 == 0) -> y e4m3 bytes = sat(x * scale[0]); scale (device, nullable = 1)
+ *                         and amax (device, nullable): max|x| is recorded with an atomic max (delayed scaling, no host round trip)
+ *   cddmsl_conv_fwd_fp8   e4m3 x [Nimg][Hi][Wi][Cin] * e4m3 w [Cout][KH][KW][Cin], stride 1 -> bf16 (f32 with out_f32) y with the
+ *                         epilogue of cddmsl_conv_fwd (scale / bias f32 per channel -- the caller folds both dequantisation
+ *                         factors into scale --, bf16 residual, ReLU, bf16 ReLU mask); v_mfma_scale_f32_32x32x64_f8f6f4, f32 accumulate.
+ *                         Cin % 128 == 0, Cout % 256 == 0, <= 31 taps: other shapes are CDDMSL_ERR_ARG
+ *   cddmsl_fp8_dot_nt     c [R][ldc] f32 (columns < N) = alpha[0] * a [R][K] . b [N][K]^T, N <= 32, K % 64 == 0
+ *   y8 / q8 / amax8 (nullable together; cddmsl_conv_fwd_fp8 and cddmsl_conv_fwd_q8): a second output y8 [M][Cout] = e4m3 of
+ *                         sat(y * q8[0]) for the NEXT convolution, written by the same epilogue (no separate quantisation pass);
+ *                         max|y| goes to amax8.  Every amax buffer is 64 floats (atomics are spread by block; the owner takes the max).
+ *   cddmsl_conv_fwd_q8    = cddmsl_conv_fwd for bf16 with that second output; only launches the 256x256 kernel takes */
+int cddmsl_quantize_fp8(const void* x, void* y, const float* scale, float* amax, long numel, int src_dtype, void* stream);
+int cddmsl_conv_fwd_fp8(const void* x, const void* w, void* y, const float* scale, const float* bias, const void* residual,
+                        const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int pad, int relu,
+                        int out_f32, void* y8, const float* q8, float* amax8, void* stream);
+int cddmsl_conv_fwd_q8(const void* x, const void* w, void* y, const float* scale, const float* bias, const void* residual,
+                       const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                       int relu, void* y8, const float* q8, float* amax8, void* stream);
+int cddmsl_fp8_dot_nt(const void* a, const void* b, float* c, const float* alpha, int R, int N, int K, int ldc, void* stream);
+
 /* ---- RoIAlign  (layers/roi_align.py:49-65 -> torchvision.ops.roi_align; modeling/poolers.py:190-229) --------- */
 /* y_pooled (nullable, [K][ph/2][pw/2][C], ph and pw even): AvgPool2d(2) of y, formed from the rounded outputs in the pooling
  * kernel's order -- what the first Bottleneck of the RoI head's layer4 reads on its downsample path (clip_backbone.py:45-52) */
@@ -80,10 +104,12 @@ int cddmsl_roi_align_backward(const void* dy, const float* rois, const int* roi_
  *   _affine:  y = relu?(scale[c] * roi_align(x)[.., c] + bias[c])  (FrozenBN + ReLU of that conv; scale / bias nullable),
  *             y nullable when only y_pooled (the downsample path's AvgPool2d(2) of the crops) is wanted;
  *   _backward_pooled: dy is the gradient of the pooled map [K][ph][pw][C] (RoIAlign grid 2ph x 2pw): roi_align_backward of the
- *             AvgPool2d backward of dy, without forming it. */
+ *             AvgPool2d backward of dy, without forming it;
+ *             y8 / q8 / amax8 (nullable, bf16 only): e4m3 copy of y for the consuming convolution, as cddmsl_conv_fwd_q8. */
 int cddmsl_roi_align_forward_affine(const void* x, const float* rois, void* y, void* y_pooled, const float* scale,
                                     const float* bias, int relu, int N, int C, int H, int W, int K, int ph, int pw,
-                                    float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
+                                    float spatial_scale, int sampling_ratio, int aligned, int dtype, void* y8, const float* q8,
+                                    float* amax8, void* stream);
 int cddmsl_roi_align_backward_pooled(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,
                                      float* ws_ax, int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw,
                                      float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
