@@ -2289,9 +2289,26 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   // time of the short backbone layers (measured: 150 -> 67 us at M = 66 400, N = 1024, K = 256).
   const char* eb = getenv("CDDMSL_WGRAD_BLOCKS");                  // tuning knob (A/B runs): target number of blocks
   const long target = eb ? atol(eb) : ((KH == 1 && KW == 1) ? 512 : 1024);
-  long want = (target + tiles - 1) / tiles;
   long maxs = (total_mt + 7) / 8;
-  long splits = want < 1 ? 1 : (want > maxs ? maxs : want);
+  // ... and a WHOLE number of 512-block rounds (two resident blocks per CU): with 9 output tiles (128 x 1152) a target of 1024
+  // gave 114 splits = 1026 blocks, i.e. a third round for two blocks.  Candidates: the largest split count that stays inside
+  // r rounds, r = the target's rounds and one more; the one whose last round is fullest wins (fewer rounds on ties).
+  long splits = 1;
+  {
+    const long r0 = (target + 511) / 512;
+    double best = -1.0;
+    for (long r = r0; r <= r0 + 1; ++r) {
+      long c = (512 * r) / tiles;
+      if (c < 1) c = 1;
+      if (c > maxs) c = maxs;
+      const int mps = (int)((total_mt + c - 1) / c);
+      const long real = (total_mt + mps - 1) / mps, blocks = tiles * real, rounds = (blocks + 511) / 512;
+      const double eff = (double)blocks / (512.0 * rounds);
+      if (eff > best + 0.03) { best = eff; splits = c; }
+      if (c == maxs) break;
+    }
+    if (eb) { splits = (target + tiles - 1) / tiles; if (splits > maxs) splits = maxs; }
+  }
   if (splits < 1) splits = 1;
   a.mtiles_per_split = (int)((total_mt + splits - 1) / splits);
   splits = (total_mt + a.mtiles_per_split - 1) / a.mtiles_per_split;
