@@ -124,6 +124,29 @@ class PreparedWeight:
 # ------------------------------------------------------------------------------------------------
 # OCP e4m3 (fp8) forward GEMMs -- BASELINE.json configs[4]; no counterpart in the reference (AMP off, config/defaults.py:697)
 # ------------------------------------------------------------------------------------------------
+class Fp8Slot:
+    """one tensor's scaling state (views into ``Fp8Scales.buf``).  ``calibrated`` (host flag): the first time a tensor is
+    quantised its scale is taken from the tensor itself (one extra reduction, no host sync) -- a gradient of magnitude 1e-6 would
+    otherwise flush to zero under the initial scale of 1, and so would everything computed from it, so that a chain of L
+    layers needed L steps to find its scales.  Until then no producer writes the e4m3 copy on the consumer's behalf."""
+    __slots__ = ("scale", "deq", "amax", "calibrated")
+
+    def __init__(self, scale, deq, amax):
+        self.scale, self.deq, self.amax, self.calibrated = scale, deq, amax, False
+
+    def calibrate(self, t):
+        if not self.calibrated:
+            amax = t.detach().abs().amax().float().view(1)
+            sc = torch.where(amax > 0, hip.FP8_MAX / amax.clamp_min(1e-30), torch.ones_like(amax))
+            self.scale.copy_(sc)
+            self.deq.copy_(1.0 / sc)
+            self.calibrated = True
+
+    def emit(self):
+        """(scale, amax) for a producing launch -- only once this slot has a scale of its own"""
+        return (self.scale, self.amax) if self.calibrated else None
+
+
 class Fp8Scales:
     """Per-tensor delayed scaling, entirely on the device: slot = (scale, 1/scale, 64 words of running max|x|).  A quantising
     launch (the quantise kernel, or the epilogue of the convolution / RoIAlign launch that produces the tensor) reads its slot's
@@ -143,7 +166,7 @@ class Fp8Scales:
         assert self.used < self.CAP
         row = self.buf[self.used]
         self.used += 1
-        return row[0:1], row[1:2], row[2:]            # scale [1], dequantisation factor [1], amax words [64]
+        return Fp8Slot(row[0:1], row[1:2], row[2:])   # scale [1], dequantisation factor [1], amax words [64]
 
     def roll(self, margin=1.0):
         if self.buf is None or self.used == 0:
@@ -175,7 +198,7 @@ def fp8_weight(pw):
 def fp8_act_slot(pw):
     """the delayed-scaling slot of the activation tensor that feeds this weight's convolution"""
     sl = getattr(pw, "_fp8_slot", None)
-    if sl is None or sl[0].device != pw.param.device:
+    if sl is None or sl.scale.device != pw.param.device:
         pw._fp8_slot = sl = FP8_SCALES.slot(pw.param.device)
     return sl
 
@@ -196,8 +219,7 @@ def fp8_emit_for(consumer_pw, out_shape, pad, fp8, producer_cout=None, producer_
     M = out_shape[0] * out_shape[1] * out_shape[2]
     if producer_cout is not None and not hip.conv_emit8_ok(M, producer_cout, producer_taps, 1):
         return None
-    s_x, _, amax = fp8_act_slot(consumer_pw)
-    return (s_x, amax)
+    return fp8_act_slot(consumer_pw).emit()
 
 
 def conv_fwd_auto(x, pw, scale=None, bias=None, fp8=False, emit8=None, **kw):
@@ -211,11 +233,15 @@ def conv_fwd_auto(x, pw, scale=None, bias=None, fp8=False, emit8=None, **kw):
         Cout = _ohwi(pw.param).shape[0]
         pad = kw.get("pad", 0)
         if _fp8_eligible(pw, x.shape, pad):
-            s_x, d_x, amax = fp8_act_slot(pw)
+            sl = fp8_act_slot(pw)
             made = getattr(x, "_fp8", None)
-            x8 = made[0] if made is not None and made[1] == s_x.data_ptr() else hip.quantize_fp8(x, s_x, amax)
+            if made is not None and made[1] == sl.scale.data_ptr():
+                x8 = made[0]
+            else:
+                sl.calibrate(x)
+                x8 = hip.quantize_fp8(x, sl.scale, sl.amax)
             w8, d_w = fp8_weight(pw)
-            eff = (d_x * d_w) * scale if scale is not None else (d_x * d_w).expand(Cout).contiguous()
+            eff = (sl.deq * d_w) * scale if scale is not None else (sl.deq * d_w).expand(Cout).contiguous()
             return hip.conv_fwd_fp8(x8, w8, eff, bias, kw.get("residual"), kw.get("relu", False), kw.get("relu_mask"), pad, emit8=emit8)
     wf, _ = pw.get(T, need_dgrad=False)
     if emit8 is not None:
@@ -226,6 +252,70 @@ def conv_fwd_auto(x, pw, scale=None, bias=None, fp8=False, emit8=None, **kw):
         if not (T == torch.bfloat16 and hip.conv_emit8_ok(M, Cout, KH, KW, (Cin * 2 // 16) % 8 == 0) and kw.get("stride", 1) == 1):
             emit8 = None
     return hip.conv_fwd(x, wf, scale, bias, emit8=emit8, **kw)
+
+
+def fp8_weight_d(pw, wd):
+    """e4m3 copy of the prepared input-gradient weights ``wd`` ([Cin, KH, KW, Cout]: flipped, transposed, FrozenBN-scaled) and
+    its dequantisation factor; cached per step like ``fp8_weight``"""
+    key = (-1 if pw.frozen else _STEP[0], wd.data_ptr(), pw.param._version, _LOAD_GEN[0])
+    c = getattr(pw, "_fp8d", None)
+    if c is None or c[0] != key:
+        amax = wd.abs().amax().float().clamp_min(1e-20).view(1)
+        pw._fp8d = c = (key, hip.quantize_fp8(wd, hip.FP8_MAX / amax), amax / hip.FP8_MAX)
+    return c[1], c[2]
+
+
+def fp8_slot_of(owner, name):
+    """a delayed-scaling slot attached to ``owner`` (a PreparedWeight or BlockParams) under ``name``"""
+    sl = getattr(owner, name, None)
+    dev = (owner.param if hasattr(owner, "param") else owner.w[0]).device
+    if sl is None or sl.scale.device != dev:
+        sl = FP8_SCALES.slot(dev)
+        setattr(owner, name, sl)
+    return sl
+
+
+def dgrad_auto(g, pw, fp8=False, slot=None, emit8=None, **kw):
+    """Input gradient of a convolution = ``hip.conv_fwd`` of the output gradient with the prepared (flipped / transposed /
+    FrozenBN-scaled) weights; with ``fp8`` on shapes the e4m3 kernel takes and wins on, both operands in e4m3: the gradient's
+    copy comes from its producer (``g._fp8``, made with ``slot``) or one quantisation pass, the weights' from ``fp8_weight_d``.
+    ``slot``: the gradient tensor's delayed-scaling slot (shared by all its consumers).  kw: pad, residual, relu_mask,
+    residual_pooled."""
+    T = g.dtype
+    _, wd = pw.get(T, True)
+    if fp8 and T == torch.bfloat16 and slot is not None and not kw.get("residual_pooled", False):
+        Cout_d, KH, KW, Cin_d = wd.shape
+        pad = kw.get("pad", 0)
+        N, H, W, _ = g.shape
+        M = N * (H + 2 * pad - KH + 1) * (W + 2 * pad - KW + 1)
+        if hip.conv_fwd_fp8_ok(M, Cin_d, Cout_d, KH, KW, pad):
+            made = getattr(g, "_fp8", None)
+            if made is not None and made[1] == slot.scale.data_ptr():
+                g8 = made[0]
+            else:
+                slot.calibrate(g)
+                g8 = hip.quantize_fp8(g, slot.scale, slot.amax)
+            wd8, d_w = fp8_weight_d(pw, wd)
+            return hip.conv_fwd_fp8(g8, wd8, (slot.deq * d_w).expand(Cout_d).contiguous(), None, kw.get("residual"), False, kw.get("relu_mask"),
+                                    pad, emit8=emit8)
+    if emit8 is not None:
+        Cout_d, KH, KW, Cin_d = wd.shape
+        N, H, W, _ = g.shape
+        pad = kw.get("pad", 0)
+        M = N * (H + 2 * pad - KH + 1) * (W + 2 * pad - KW + 1)
+        if not (T == torch.bfloat16 and hip.conv_emit8_ok(M, Cout_d, KH, KW, (Cin_d * 2 // 16) % 8 == 0) and not kw.get("residual_pooled", False)):
+            emit8 = None
+    return hip.conv_fwd(g, wd, emit8=emit8, **kw)
+
+
+def _fp8_dgrad_wanted(pw, g_shape, pad, fp8):
+    """would ``dgrad_auto`` run the e4m3 kernel for a gradient of ``g_shape`` through ``pw``?"""
+    if not fp8:
+        return False
+    Cout, KH, KW, Cin = _ohwi(pw.param).shape          # the input-gradient conv maps Cout -> Cin channels
+    N, H, W, _ = g_shape
+    M = N * (H + 2 * pad - KH + 1) * (W + 2 * pad - KW + 1)
+    return hip.conv_fwd_fp8_ok(M, Cout, Cin, KH, KW, pad)
 
 
 def cat_prepared(weights, dtype):
@@ -418,24 +508,29 @@ def _block_forward(x, bp, save, px_given=None, next_pw=None):
     return out, ((o1, o2, p2 if pool else None, px if pool else None) if save else None)
 
 
-def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x):
+def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None):
     """gs = dL/d(pre-ReLU sum) of this block (already masked by out>0).  Returns dL/dx, masked by x>0 when
-    ``mask_x`` (x is the previous block's post-ReLU output) so it is directly the previous block's ``gs``."""
+    ``mask_x`` (x is the previous block's post-ReLU output) so it is directly the previous block's ``gs``.
+    fp8 configuration: the input-gradient convolutions with a long reduction (conv3's, conv2's, the downsample conv's) run on
+    e4m3 operands (``dgrad_auto``); ``prev_bp`` = the block that receives the returned gradient as ITS ``gs`` (its e4m3 copy is
+    then written by this block's last launch)."""
     T = x.dtype
     (s1, _), (s2, _), (s3, _), bnd = bp.bn
     pool = bp.stride > 1
+    f8 = bp.fp8 and T == torch.bfloat16
     w1p, w2p, w3p, wdp = bp.w
     shp = lambda w: _ohwi(w).shape
+    gs_slot = fp8_slot_of(bp, "_fp8_gs") if f8 else None
+    d2_slot = fp8_slot_of(bp.pw[1], "_fp8_g") if f8 else None
     hip.conv_wgrad(p2 if pool else o2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
-    _, w3d = bp.pw[2].get(T, True)
     if pool:
-        dp2 = hip.conv_fwd(gs, w3d)
+        dp2 = dgrad_auto(gs, bp.pw[2], f8, gs_slot)
         dpre2 = hip.avgpool2_bwd(dp2, tuple(o2.shape), mask=o2)
     else:
-        dpre2 = hip.conv_fwd(gs, w3d, relu_mask=o2)
+        e8 = d2_slot.emit() if f8 and _fp8_dgrad_wanted(bp.pw[1], o2.shape, 1, f8) else None
+        dpre2 = dgrad_auto(gs, bp.pw[2], f8, gs_slot, emit8=e8, relu_mask=o2)
     hip.conv_wgrad(o1, dpre2, shp(w2p), s2, pad=1, out=_ohwi(_grad_buf(w2p)))
-    _, w2d = bp.pw[1].get(T, True)
-    dpre1 = hip.conv_fwd(dpre2, w2d, pad=1, relu_mask=o1)
+    dpre1 = dgrad_auto(dpre2, bp.pw[1], f8, d2_slot, pad=1, relu_mask=o1)
     hip.conv_wgrad(x, dpre1, shp(w1p), s1, out=_ohwi(_grad_buf(w1p)))
     if wdp is not None:
         hip.conv_wgrad(px if pool else x, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
@@ -443,8 +538,7 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x):
         return None
     pooled = False
     if wdp is not None:
-        _, wdd = bp.pw[3].get(T, True)
-        dxb = hip.conv_fwd(gs, wdd)
+        dxb = dgrad_auto(gs, bp.pw[3], f8, gs_slot)
         if pool:
             # the downsample path's input gradient stays at pooled resolution: conv1's dgrad epilogue adds a quarter of each
             # row's pooled pixel (AvgPool2d backward fused; saves writing and re-reading the full-resolution tensor)
@@ -453,8 +547,10 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x):
                 dxb = hip.avgpool2_bwd(dxb, tuple(x.shape))
     else:
         dxb = gs
-    _, w1d = bp.pw[0].get(T, True)
-    return hip.conv_fwd(dpre1, w1d, residual=dxb, relu_mask=x if mask_x else None, residual_pooled=pooled)
+    e8 = None
+    if f8 and prev_bp is not None and prev_bp.fp8 and not pooled and _fp8_dgrad_wanted(prev_bp.pw[2], x.shape, 0, True):
+        e8 = fp8_slot_of(prev_bp, "_fp8_gs").emit()  # the returned gradient is prev_bp's gs: write its e4m3 copy here
+    return dgrad_auto(dpre1, bp.pw[0], False, None, emit8=e8, residual=dxb, relu_mask=x if mask_x else None, residual_pooled=pooled)
 
 
 class ResStageFn(torch.autograd.Function):
@@ -479,7 +575,7 @@ class ResStageFn(torch.autograd.Function):
         gs = g.contiguous() if ctx.out_grad_premasked else hip.relu_bwd(g.contiguous(), saved[-1])
         for i in range(len(blocks) - 1, -1, -1):
             x, o1, o2, p2, px = saved[5 * i: 5 * i + 5]
-            gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0)
+            gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0, prev_bp=blocks[i - 1] if i > 0 else None)
         return gs, None, None, None, None
 
 
@@ -565,7 +661,7 @@ class RoIStageFn(torch.autograd.Function):
         gs = g.contiguous() if premasked else hip.relu_bwd(g.contiguous(), st[-1])
         for i in range(len(blocks) - 1, 0, -1):
             o1, o2, p2, px = st[5 * i: 5 * i + 4]
-            gs = _block_backward(gs, st[5 * i - 1], o1, o2, p2, px, blocks[i], True, mask_x=True)
+            gs = _block_backward(gs, st[5 * i - 1], o1, o2, p2, px, blocks[i], True, mask_x=True, prev_bp=blocks[i - 1])
         bp = blocks[0]
         o1, o2, p2, px = st[0:4]
         T = o1.dtype
@@ -573,15 +669,15 @@ class RoIStageFn(torch.autograd.Function):
         w1p, w2p, w3p, wdp = bp.w
         shp = lambda w: _ohwi(w).shape
         K, E = rois.shape[0], (0 if extra is None else extra.shape[0])
+        f8 = bp.fp8 and T == torch.bfloat16
+        gs_slot = fp8_slot_of(bp, "_fp8_gs") if f8 else None
+        d2_slot = fp8_slot_of(bp.pw[1], "_fp8_g") if f8 else None
         hip.conv_wgrad(p2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
-        _, w3d = bp.pw[2].get(T, True)
-        dpre2 = hip.avgpool2_bwd(hip.conv_fwd(gs, w3d), tuple(o2.shape), mask=o2)
+        dpre2 = hip.avgpool2_bwd(dgrad_auto(gs, bp.pw[2], f8, gs_slot), tuple(o2.shape), mask=o2)
         hip.conv_wgrad(o1, dpre2, shp(w2p), s2, pad=1, out=_ohwi(_grad_buf(w2p)))
-        _, w2d = bp.pw[1].get(T, True)
-        dpre1 = hip.conv_fwd(dpre2, w2d, pad=1, relu_mask=o1)                               # [K+E,14,14,planes] wrt bn1's output
+        dpre1 = dgrad_auto(dpre2, bp.pw[1], f8, d2_slot, pad=1, relu_mask=o1)                # [K+E,14,14,planes] wrt bn1's output
         hip.conv_wgrad(px, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
-        _, wdd = bp.pw[3].get(T, True)
-        dxb = hip.conv_fwd(gs, wdd)                                                          # [K+E,7,7,C] wrt the pooled crops
+        dxb = dgrad_auto(gs, bp.pw[3], f8, gs_slot)                                          # [K+E,7,7,C] wrt the pooled crops
         # back across the pooling: gather at `planes` channels, then conv1's gradients on the feature map (s1 rides in the
         # weight-gradient scale and in the prepared input-gradient weights, as for every conv of a stage)
         N, H, W, C = feat.shape

@@ -105,9 +105,10 @@ def test_fp8_step_is_close_to_f32_step_with_forced_indices(monkeypatch):
     elsewhere and in the whole backward) against the exact-f32 HIP step with the f32 run's proposals forced in (same sampled
     anchors / RoIs / region picks).  Two steps: the first quantises with unit scales, the second with the scales rolled from the
     first step's recorded maxima -- the comparison is made on the SECOND.  Stated tolerance: e4m3 carries 3 mantissa bits
-    (2^-4 relative per element); measured here: losses within ~2 %, gradient direction (cosine) >= 0.97 on the worst tensor."""
+    (2^-4 relative per element); measured here: losses within ~2 %, gradient cosine >= 0.9918 on every backbone tensor, 0.9465 on
+    the RPN's box-delta head (asserted: 6 % + 5e-3 on losses, cosine >= 0.92).  Input-gradient convolutions run in e4m3 as well."""
     monkeypatch.setenv("CDDMSL_FP8_MIN_TILES", "1")
-    monkeypatch.setenv("CDDMSL_FP8_MIN_K", "128")
+    # (the reduction-length rule stays the production one, K >= 2048: which convolutions run in e4m3 is part of the configuration)
     from cddmsl_amd import hip, layers, synthetic
     from test_gpu_e2e import ProposalTape, _build, _cfg
     from cddmsl_amd.engine import SimpleTrainer
