@@ -65,6 +65,22 @@ for kern, name in (("k_conv_fwd256", "k_conv_fwd256"), ("k_conv_fwdI", "k_conv_f
                          "MFMA share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE / 8 / dispatch duration (ns)"}
 json.dump(out, open('$OUT/${TAG}_traffic.json', 'w'), indent=1)
 print(json.dumps(out))
+# per-shape view of the dominant kernel: dispatches grouped by grid size (= number of 256x256 tiles)
+def by_grid(rows, counter, mul):
+    d = collections.defaultdict(list)
+    for r in rows:
+        if "k_conv_fwd256" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            d[int(r["Grid_Size"]) // 512].append(mul * float(r["Counter_Value"]) * 1024 / 1e6)
+    return d
+fe, wr = by_grid(fetch, "FETCH_SIZE", 2.0), by_grid(write, "WRITE_SIZE", 1.0)
+with open('$OUT/${TAG}_traffic_by_grid.txt', 'w') as f:
+    f.write("# k_conv_fwd256: fabric-side traffic per dispatch (MB; FETCH_SIZE x2, WRITE_SIZE), dispatches grouped by tile count.\n"
+            "# FETCH_SIZE counts the L2's memory-side requests INCLUDING Infinity-Cache hits (MI355X_MICROARCH.md, HBM): it bounds HBM reads from above.\n"
+            "# tiles  dispatches  fetch: min / quartiles / max   write: distinct values\n")
+    for t in sorted(fe, key=lambda t: -sum(fe[t])):
+        a = sorted(fe[t]); w = sorted(set(round(x) for x in wr.get(t, [0.0])))
+        q = [a[0], a[len(a) // 4], a[len(a) // 2], a[(3 * len(a)) // 4], a[-1]]
+        f.write("%6d %4d   fetch %s   write %s\n" % (t, len(a), " ".join("%7.0f" % x for x in q), w))
 PY
 python3 tools/shape_profile.py 16 > $OUT/${TAG}_shape_profile.txt 2> $OUT/shape.err
 echo "shape profile done"
