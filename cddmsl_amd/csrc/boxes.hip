@@ -359,6 +359,49 @@ extern "C" int cddmsl_nms(const float* boxes, const unsigned char* valid, unsign
   return launch_status();
 }
 
+// torchvision.ops.nms(boxes [K,4], scores [K], iou_threshold) -> kept indices (int64, descending score) as the reference calls it
+// (layers/nms.py:6-7,30,35): candidates in ANY order.  Composition of the stages above on caller-provided scratch: stable radix
+// sort of the scores, gather of the boxes, 64-bit wave-mask NMS, map of the kept positions back to input indices.
+// temp == NULL: *temp_bytes receives the scratch size.  keep: K int64 (first *nkeep valid, the rest -1), nkeep: 1 int (device).
+__global__ void k_nms_gather(const float* boxes, const int* order, float* sorted, unsigned char* valid, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  const f32x4 b = ((const f32x4*)boxes)[order[i]];
+  ((f32x4*)sorted)[i] = b;
+  valid[i] = 1;
+}
+__global__ void k_nms_unmap(const int* keep32, const int* nkeep, const int* order, long* keep, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  keep[i] = i < nkeep[0] ? (long)order[keep32[i]] : -1L;
+}
+extern "C" int cddmsl_nms_anyorder(const float* boxes, const float* scores, long* keep, int* nkeep, int K, float iou_threshold,
+                                   void* temp, size_t* temp_bytes, void* stream) {
+  if (K < 0 || K > 64 * NMS_MAXW || !temp_bytes) return CDDMSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 0) { if (temp) return hipMemsetAsync(nkeep, 0, sizeof(int), st) == hipSuccess ? CDDMSL_OK : CDDMSL_ERR_LAUNCH; *temp_bytes = 0; return CDDMSL_OK; }
+  size_t sort_bytes = 0;
+  int rc = cddmsl_sort_desc(nullptr, nullptr, nullptr, nullptr, nullptr, 1, K, nullptr, &sort_bytes, stream);
+  if (rc != CDDMSL_OK) return rc;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const int nw = (K + 63) / 64;
+  const size_t o_keys = al(sort_bytes), o_idx = o_keys + al((size_t)K * 4), o_ord = o_idx + al((size_t)K * 4), o_box = o_ord + al((size_t)K * 4),
+               o_val = o_box + al((size_t)K * 16), o_msk = o_val + al((size_t)K), o_k32 = o_msk + al((size_t)K * nw * 8), total = o_k32 + al((size_t)K * 4);
+  if (!temp) { *temp_bytes = total; return CDDMSL_OK; }
+  if (*temp_bytes < total) return CDDMSL_ERR_ARG;
+  char* t = (char*)temp;
+  size_t sb = sort_bytes;
+  rc = cddmsl_sort_desc(scores, (float*)(t + o_keys), (int*)(t + o_idx), (int*)(t + o_ord), nullptr, 1, K, t, &sb, stream);
+  if (rc != CDDMSL_OK) return rc;
+  const unsigned blocks = (unsigned)((K + 255) / 256);
+  k_nms_gather<<<dim3(blocks), dim3(256), 0, st>>>(boxes, (const int*)(t + o_ord), (float*)(t + o_box), (unsigned char*)(t + o_val), K);
+  rc = cddmsl_nms((const float*)(t + o_box), (const unsigned char*)(t + o_val), (unsigned long long*)(t + o_msk), (int*)(t + o_k32), nkeep, 1, K,
+                  iou_threshold, K, stream);
+  if (rc != CDDMSL_OK) return rc;
+  k_nms_unmap<<<dim3(blocks), dim3(256), 0, st>>>((const int*)(t + o_k32), nkeep, (const int*)(t + o_ord), keep, K);
+  return launch_status();
+}
+
 // One image: gt [G][4], preds [P][4] -> matches int64 [P], labels int8 [P].  best_ws: G uints (zeroed here).
 extern "C" int cddmsl_iou_match(const float* gt, int G, const float* preds, int P, long* matches, signed char* labels,
                                 unsigned int* best_ws, int nthr, float t0, float t1, int l0, int l1, int l2,

@@ -46,6 +46,7 @@ def _L():
         L.cddmsl_sgd_clip_step.argtypes = [vp] * 4 + [ci, vp] + [cf] * 4 + [ci, vp]
         L.cddmsl_roi_align_forward.argtypes = [vp] * 5 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_roi_align_backward.argtypes = [vp] * 7 + [ci] * 7 + [cf, ci, ci, ci, vp]
+        L.cddmsl_nms_anyorder.argtypes = [vp] * 4 + [ci, cf, vp, vp, vp]
         L.cddmsl_quantize_fp8.argtypes = [vp] * 4 + [c_long, ci, vp]
         L.cddmsl_conv_fwd_fp8.argtypes = [vp] * 7 + [ci] * 10 + [vp] * 4
         L.cddmsl_conv_fwd_q8.argtypes = [vp] * 7 + [ci] * 10 + [vp] * 4
@@ -649,6 +650,23 @@ def sort_desc(keys):
     check(_L().cddmsl_sort_desc(ptr(keys), ptr(keys_out), ptr(idx), ptr(order), ptr(offs), N, total, ptr(ws), ctypes.byref(nbytes),
                                 stream_ptr()), "cddmsl_sort_desc")
     return keys_out, order
+
+
+@_timed("nms")
+def nms_anyorder(boxes, scores, iou_threshold):
+    """torchvision.ops.nms(boxes [K,4], scores [K], thr) -> (keep int64 [K] (kept indices, descending score, then -1), nkeep int32 [1])"""
+    require_cuda(boxes, scores)
+    K = boxes.shape[0]
+    assert boxes.dtype == scores.dtype == torch.float32 and boxes.is_contiguous() and scores.is_contiguous() and scores.numel() == K
+    keep = torch.empty(K, device=boxes.device, dtype=torch.int64)
+    nkeep = torch.zeros(1, device=boxes.device, dtype=torch.int32)
+    nbytes = ctypes.c_size_t(0)
+    check(_L().cddmsl_nms_anyorder(ptr(boxes), ptr(scores), ptr(keep), ptr(nkeep), K, iou_threshold, None, ctypes.byref(nbytes), stream_ptr()),
+          "cddmsl_nms_anyorder(size)")
+    ws = workspace("nms_any", max(nbytes.value, 1), boxes.device)
+    check(_L().cddmsl_nms_anyorder(ptr(boxes), ptr(scores), ptr(keep), ptr(nkeep), K, iou_threshold, ptr(ws), ctypes.byref(nbytes), stream_ptr()),
+          "cddmsl_nms_anyorder")
+    return keep, nkeep
 
 
 @_timed("rpn_decode")

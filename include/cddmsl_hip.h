@@ -129,6 +129,11 @@ int cddmsl_rpn_decode(const int* order, const float* deltas, const float* cell, 
                       float wy, float ww, float wh, float scale_clamp, float min_size, void* stream);
 int cddmsl_nms(const float* boxes, const unsigned char* valid, unsigned long long* mask_ws, int* keep, int* nkeep, int N,
                int n, float thr, int max_keep, void* stream);
+/* torchvision.ops.nms as the reference calls it (layers/nms.py:6-7,30,35): boxes [K][4] and scores [K] in ANY order ->
+ * keep [K] int64 = indices of the kept boxes in descending-score order (entries past *nkeep are -1), nkeep [1] (device).
+ * Scratch from the caller: call with temp == NULL to get *temp_bytes.  K <= 12288. */
+int cddmsl_nms_anyorder(const float* boxes, const float* scores, long* keep, int* nkeep, int K, float iou_threshold, void* temp,
+                        size_t* temp_bytes, void* stream);
 int cddmsl_iou_match(const float* gt, int G, const float* preds, int P, long* matches, signed char* labels,
                      unsigned int* best_ws, int nthr, float t0, float t1, int l0, int l1, int l2, int allow_low_quality,
                      void* stream);

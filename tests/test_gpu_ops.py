@@ -613,3 +613,25 @@ def test_roi_align_affine_and_pooled_entry_points(dtype, tol):
     want = hip.roi_align_backward(hip.avgpool2_bwd(dy, (K, 14, 14, C)), rois, start, (N, H, W, C), 1 / 16, 0, True)
     got = hip.roi_align_backward(dy, rois, start, (N, H, W, C), 1 / 16, 0, True, pooled=True)
     assert float((got.float() - want.float()).abs().max()) <= tol * float(want.float().abs().max())
+
+
+def test_nms_with_the_torchvision_signature():
+    """cddmsl_nms_anyorder: torchvision.ops.nms(boxes, scores, thr) as layers/nms.py:30,35 calls it -- candidates in ANY order,
+    kept indices in descending-score order -- against the oracle's NMS (C restatement of the published algorithm): identical
+    keep lists incl. duplicate boxes and tied scores (stable: the earlier index wins), and the empty case."""
+    from cddmsl_amd import hip
+    from oracle import ops as oo
+    g = torch.Generator().manual_seed(17)
+    for K, thr in ((1, 0.5), (300, 0.7), (5000, 0.5)):
+        xy = torch.rand(K, 2, generator=g) * 400
+        boxes = torch.cat([xy, xy + 10 + torch.rand(K, 2, generator=g) * 120], dim=1)
+        scores = torch.rand(K, generator=g)
+        if K > 10:
+            boxes[7] = boxes[3]                       # duplicates
+            scores[11] = scores[5]                    # a tie
+        keep, nkeep = hip.nms_anyorder(boxes.cuda(), scores.cuda(), thr)
+        n = int(nkeep)
+        want = oo.nms(boxes, scores, thr)
+        assert n == len(want) and torch.equal(keep[:n].cpu(), want) and bool((keep[n:] == -1).all())
+    keep, nkeep = hip.nms_anyorder(torch.zeros(0, 4).cuda(), torch.zeros(0).cuda(), 0.5)
+    assert int(nkeep) == 0 and keep.numel() == 0
