@@ -1,7 +1,7 @@
 """Host-side rows next to the hot path (SURVEY.md 8(f)2,4): paired VOC data pipeline and checkpoint compatibility.
-CPU only.  The reference's transform classes cannot be imported here (they derive from fvcore, not installed), so the
-resize numerics are checked against the PIL call both sides make and the geometry against hand-computed values
-(parity unpinned by reference fixtures; see cddmsl_amd/data.py)."""
+CPU only.  Geometry and resize numerics are checked against hand-computed values and the PIL call both sides make, and -- round 2 --
+against a fixture produced by the reference's own transform / annotation code with fvcore's base classes stubbed
+(tests/golden/make_golden_data.py -> ref_data_transforms.npz: test_mapper_geometry_matches_reference_transforms)."""
 import os
 
 import numpy as np
@@ -189,3 +189,64 @@ def test_clip_checkpoint_name_conversion(tmp_path):
     # one checkpoint tensor claimed by two model keys is an error
     with pytest.raises(ValueError):
         convert_clip_state({"a.conv1.weight": torch.zeros(1), "b.conv1.weight": torch.zeros(1)}, {"conv1.weight": torch.zeros(1)})
+
+
+def test_mapper_geometry_matches_reference_transforms(tmp_path):
+    """cddmsl_amd/data.py against numbers produced by the reference's own ResizeShortestEdge / ResizeTransform / RandomFlip /
+    transform_instance_annotations / annotations_to_instances / filter_empty_instances (tests/golden/ref_data_transforms.npz,
+    generator tests/golden/make_golden_data.py): new sizes, PIL-resized pixels of image and twin (bit-equal), flipped result,
+    transformed + clipped + filtered boxes, and the ORDER of the random draws of a sample (short edge, then flip)."""
+    from PIL import Image
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_data_transforms.npz"))
+    for h, w, size, max_size, nh, nw in g["sizes"].tolist():
+        assert data.shortest_edge_size(h, w, size, max_size) == (nh, nw)
+    n_img = 0
+    for i in range(len(g["sizes"])):
+        h, w, size, max_size, nh, nw = g["sizes"][i].tolist()
+        flip = int(g[f"flip{i}"])
+
+        class Scripted:                                   # the mapper's two draws, scripted: this short edge, this flip decision
+            def choice(self, a):
+                return size
+
+            def uniform(self):
+                return 0.25 if flip else 0.75
+
+        cfg = get_cfg()
+        cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", (size,), "INPUT.MAX_SIZE_TRAIN", max_size, "INPUT.FORMAT", "RGB"])
+        m = data.DatasetMapper(cfg, True, Scripted())
+        if f"img{i}" in g.files:
+            img = g[f"img{i}"]
+            assert np.array_equal(data.resize_image(img, nh, nw), g[f"resized{i}"])
+            p, pt = str(tmp_path / f"a{i}.png"), str(tmp_path / f"t{i}.png")
+            Image.fromarray(img).save(p)
+            Image.fromarray(255 - img).save(pt)
+            n_img += 1
+        else:                                             # geometry only: a blank image of the right size
+            p = pt = str(tmp_path / f"b{i}.png")
+            Image.fromarray(np.zeros((h, w, 3), np.uint8)).save(p)
+        d = {"file_name": p, "data_dt_file_name": pt, "height": h, "width": w, "image_id": str(i),
+             "annotations": [{"bbox": b.tolist(), "category_id": int(c)} for b, c in zip(g[f"boxes_in{i}"], g[f"classes_in{i}"])]}
+        out = m(d)
+        assert tuple(out["image"].shape) == (3, nh, nw)
+        if f"img{i}" in g.files:
+            assert np.array_equal(out["image"].permute(1, 2, 0).numpy(), g[f"final{i}"])
+            want_twin = g[f"twin_resized{i}"][:, ::-1] if flip else g[f"twin_resized{i}"]
+            assert np.array_equal(out["image_trgt"].permute(1, 2, 0).numpy(), want_twin)
+        inst = out["instances"]
+        assert np.allclose(inst.gt_boxes.tensor.numpy(), g[f"boxes_out{i}"], rtol=0, atol=1e-4), i
+        assert np.array_equal(inst.gt_classes.numpy(), g[f"classes_out{i}"]) and len(inst) < len(g[f"boxes_in{i}"])   # the outside box is gone
+    assert n_img >= 3
+    # draw order of a sample with the shipped augmentation settings
+    cfg = get_cfg()
+    cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", tuple(range(480, 801, 32)), "INPUT.MAX_SIZE_TRAIN", 1333, "INPUT.FORMAT", "RGB"])
+    m = data.DatasetMapper(cfg, True, np.random.RandomState(321))
+    p = str(tmp_path / "z.png")
+    Image.fromarray(np.zeros((375, 500, 3), np.uint8)).save(p)
+    seen = []
+    for _ in range(16):
+        out = m({"file_name": p, "height": 375, "width": 500, "image_id": "z", "annotations": [{"bbox": [10.0, 10.0, 60.0, 50.0], "category_id": 1}]})
+        nh, nw = out["image"].shape[1:]
+        x0 = float(out["instances"].gt_boxes.tensor[0, 0])
+        seen.append((nh, nw, int(abs(x0 - (nw - 60.0 * nw / 500)) < 1e-3)))          # flipped: x0' = new_w - x1 * scale
+    assert seen == [tuple(r) for r in g["draw_sequence"].tolist()]
