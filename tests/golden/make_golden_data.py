@@ -162,5 +162,65 @@ def main():
     print("data transforms ok", out["sizes"].tolist(), out["flip_draws"].astype(int).tolist())
 
 
+MINI_VOC = {   # file id -> (width, height, [(class, difficult, xmin, ymin, xmax, ymax)])
+    "000005": (120, 90, [("chair", 0, 5, 3, 40, 50), ("person", 1, 12, 8, 49, 54)]),
+    "000007": (80, 130, [("car", 0, 1, 1, 80, 130)]),
+    "000012": (100, 100, []),
+    "2008_000003": (64, 48, [("train", 0, 10, 5, 60, 40), ("tvmonitor", 0, 2, 2, 9, 9), ("person", 0, 30, 1, 44, 48)]),
+}
+
+
+def write_mini_voc(root):
+    """the XML / split files both sides read (no images: the loaders only build paths to them)"""
+    for year in ("VOC2007", "VOC2012"):
+        base = os.path.join(root, "VOCdevkit", year)
+        os.makedirs(os.path.join(base, "Annotations"), exist_ok=True)
+        os.makedirs(os.path.join(base, "ImageSets", "Main"), exist_ok=True)
+        for fid, (w, h, objs) in MINI_VOC.items():
+            body = "".join("<object><name>%s</name><pose>Unspecified</pose><truncated>0</truncated><difficult>%d</difficult>"
+                           "<bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>" % o for o in objs)
+            with open(os.path.join(base, "Annotations", fid + ".xml"), "w") as f:
+                f.write("<annotation><folder>%s</folder><size><width>%d</width><height>%d</height><depth>3</depth></size>%s</annotation>" % (year, w, h, body))
+        for split in ("trainval", "test"):
+            with open(os.path.join(base, "ImageSets", "Main", split + ".txt"), "w") as f:
+                f.write("\n".join(MINI_VOC) + "\n")
+
+
+def voc_dicts_golden():
+    """``load_voc_DG_instances`` (data/datasets/pascal_voc.py:98-172): dataset dicts of the paired VOC + domain-twin loader"""
+    import json
+    import tempfile
+    setup_data()
+    if not hasattr(np, "str"):                    # pascal_voc.py:36,113 ``dtype=np.str`` (NumPy >= 1.24 dropped the alias of str)
+        np.str = str
+    fio = sys.modules["detectron2.utils.file_io"]
+    fio.PathManager = types.SimpleNamespace(open=open, get_local_path=lambda p: p)
+    dd = sys.modules["detectron2.data"]
+    dd.DatasetCatalog = dd.MetadataCatalog = mg._Anything
+    mg._pkg("detectron2.data.datasets", "detectron2/data/datasets")
+    pv = importlib.import_module("detectron2.data.datasets.pascal_voc")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        write_mini_voc(tmp)
+        cwd = os.getcwd()
+        os.chdir(tmp)                             # relative paths in the fixture
+        try:
+            for year in ("VOC2007", "VOC2012"):
+                for split, dt in (("trainval", "clipart"), ("trainval", None), ("test", "clipart")):
+                    dicts = pv.load_voc_DG_instances(os.path.join("VOCdevkit", year), split, pv.CLASS_NAMES, dt)
+                    for d in dicts:
+                        for a in d["annotations"]:
+                            a["bbox_mode"] = int(a["bbox_mode"])
+                    out["%s|%s|%s" % (year, split, dt)] = dicts
+        finally:
+            os.chdir(cwd)
+    json.dump({"mini_voc": {k: [v[0], v[1], [list(o) for o in v[2]]] for k, v in MINI_VOC.items()}, "dicts": out},
+              open(os.path.join(HERE, "ref_voc_dicts.json"), "w"), indent=0)
+    print("voc dicts ok", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if "voc" in sys.argv[1:]:
+        voc_dicts_golden()
+    else:
+        main()

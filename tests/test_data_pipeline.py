@@ -250,3 +250,32 @@ def test_mapper_geometry_matches_reference_transforms(tmp_path):
         x0 = float(out["instances"].gt_boxes.tensor[0, 0])
         seen.append((nh, nw, int(abs(x0 - (nw - 60.0 * nw / 500)) < 1e-3)))          # flipped: x0' = new_w - x1 * scale
     assert seen == [tuple(r) for r in g["draw_sequence"].tolist()]
+
+
+def test_voc_dataset_dicts_match_reference_loader(tmp_path, monkeypatch):
+    """data.load_voc_instances against the dataset dicts the reference's own ``load_voc_DG_instances`` built from the same
+    annotation files (tests/golden/ref_voc_dicts.json, generator make_golden_data.py voc): file and twin paths, ids, sizes,
+    category ids, the xmin / ymin - 1 convention -- VOC2007 and VOC2012, training splits with and without a twin directory, test split."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_voc_dicts.json")))
+    for year in ("VOC2007", "VOC2012"):
+        base = tmp_path / "VOCdevkit" / year
+        (base / "Annotations").mkdir(parents=True)
+        (base / "ImageSets" / "Main").mkdir(parents=True)
+        for fid, (w, h, objs) in fx["mini_voc"].items():
+            body = "".join("<object><name>%s</name><difficult>%d</difficult><bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+                           % tuple(o) for o in objs)
+            (base / "Annotations" / (fid + ".xml")).write_text("<annotation><size><width>%d</width><height>%d</height></size>%s</annotation>" % (w, h, body))
+        for split in ("trainval", "test"):
+            (base / "ImageSets" / "Main" / (split + ".txt")).write_text("\n".join(fx["mini_voc"]) + "\n")
+    monkeypatch.chdir(tmp_path)
+    for key, want in fx["dicts"].items():
+        year, split, dt = key.split("|")
+        got = data.load_voc_instances(os.path.join("VOCdevkit", year), split, CLASSES, dt_data=None if dt == "None" else dt)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert set(a) == set(b), (key, set(a) ^ set(b))
+            for k in ("file_name", "image_id", "height", "width"):
+                assert a[k] == b[k], (key, k)
+            assert a.get("data_dt_file_name") == b.get("data_dt_file_name")
+            assert [(x["category_id"], x["bbox"]) for x in a["annotations"]] == [(x["category_id"], x["bbox"]) for x in b["annotations"]]
