@@ -219,8 +219,39 @@ def voc_dicts_golden():
     print("voc dicts ok", {k: len(v) for k, v in out.items()})
 
 
+def samplers_golden():
+    """``TrainingSampler`` (data/samplers/distributed_sampler.py:12-54: one seeded permutation stream shared by all ranks, rank r
+    takes indices[r::W]) and ``AspectRatioGroupedDataset`` (data/common.py:152-186: two buckets, a batch leaves when its bucket is full)"""
+    import itertools
+    import json
+    setup_data()
+    comm = sys.modules["detectron2.utils.comm"]
+    mg._pkg("detectron2.data.samplers", "detectron2/data/samplers")
+    ser = types.ModuleType("detectron2.utils.serialize")
+    ser.PicklableWrapper = mg._Anything
+    sys.modules["detectron2.utils.serialize"] = ser
+    ds = importlib.import_module("detectron2.data.samplers.distributed_sampler")
+    cm = importlib.import_module("detectron2.data.common")
+    out = {"sampler": {}}
+    for world in (1, 2, 3):
+        for rank in range(world):
+            comm.get_rank, comm.get_world_size = (lambda r=rank: r), (lambda w=world: w)
+            for size, seed, shuffle in ((11, 7, True), (5, 0, True), (4, 3, False)):
+                sm = ds.TrainingSampler(size, shuffle=shuffle, seed=seed)
+                out["sampler"]["%d|%d|%d|%d|%d" % (world, rank, size, seed, int(shuffle))] = list(itertools.islice(iter(sm), 40))
+    g = np.random.RandomState(9)
+    items = [{"id": i, "width": int(w), "height": int(h)} for i, (w, h) in enumerate(zip(g.randint(50, 200, 37), g.randint(50, 200, 37)))]
+    items[3]["width"] = items[3]["height"]                       # a square image goes with the "w <= h" bucket
+    out["items"] = items
+    out["groups"] = {str(b): [[d["id"] for d in batch] for batch in cm.AspectRatioGroupedDataset(items, b)] for b in (1, 2, 4)}
+    json.dump(out, open(os.path.join(HERE, "ref_samplers.json"), "w"))
+    print("samplers ok", len(out["sampler"]), {k: len(v) for k, v in out["groups"].items()})
+
+
 if __name__ == "__main__":
-    if "voc" in sys.argv[1:]:
+    if "samplers" in sys.argv[1:]:
+        samplers_golden()
+    elif "voc" in sys.argv[1:]:
         voc_dicts_golden()
     else:
         main()

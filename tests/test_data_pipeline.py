@@ -279,3 +279,20 @@ def test_voc_dataset_dicts_match_reference_loader(tmp_path, monkeypatch):
                 assert a[k] == b[k], (key, k)
             assert a.get("data_dt_file_name") == b.get("data_dt_file_name")
             assert [(x["category_id"], x["bbox"]) for x in a["annotations"]] == [(x["category_id"], x["bbox"]) for x in b["annotations"]]
+
+
+def test_sampler_streams_and_grouping_match_reference():
+    """``ref_samplers.json`` (tests/golden/make_golden_data.py samplers): index streams of the reference's ``TrainingSampler``
+    (data/samplers/distributed_sampler.py:12-54) for worlds 1-3, shuffled and not, and the batches its
+    ``AspectRatioGroupedDataset`` (data/common.py:152-186) forms from 37 images of mixed orientation."""
+    import itertools
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_samplers.json")))
+    for key, want in ref["sampler"].items():
+        world, rank, size, seed, shuffle = (int(v) for v in key.split("|"))
+        got = list(itertools.islice(iter(data.TrainingSampler(size, bool(shuffle), seed, rank, world)), len(want)))
+        assert got == want, key
+    items = [{"id": d["id"], "image": torch.empty(3, d["height"], d["width"], dtype=torch.uint8)} for d in ref["items"]]
+    for b, want in ref["groups"].items():
+        got = [[d["id"] for d in batch] for batch in data.aspect_ratio_batches(iter(items), int(b))]
+        assert got == want, b
