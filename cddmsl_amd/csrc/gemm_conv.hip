@@ -87,6 +87,9 @@ struct ConvArgs {
 #ifdef CDDMSL_STAMPS
   unsigned long long* stamps;   // diagnostic build only (scratch/k256.hip): per-wave cycle sums of the phase segments
 #endif
+#ifdef CDDMSL_TILE_STAMPS
+  unsigned long long* tstamps = nullptr;  // diagnostic build only (tools/tile_stamps.py): per wave, 100 MHz s_memrealtime stamps at entry / loop start / loop end / exit
+#endif
 };
 
 template <typename T> struct Mma;
@@ -1701,10 +1704,17 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, (int)soff, 0, 0);
 }
 
-template <typename T, bool TAPS, bool RPOOL = false>
+// EPI: which optional epilogue operands exist, as a COMPILE-TIME fact (bit 0 residual rows, bit 1 ReLU-mask rows; bf16 output, no
+// e4m3 copy, no f32 residual stream) or -1 = decided at run time (every other combination, and the exact-f32 instantiations).
+// With run-time flags every row of a pass is a chain of uniform branches: hipcc then neither interleaves the rows nor counts
+// its vmcnt waits across them -- passes 2 and 3 waited vmcnt(0) for their residual rows, i.e. for the previous pass's stores.
+template <typename T, bool TAPS, bool RPOOL = false, int EPI = -1>
 __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2 * 2 * 2 * 128 * KCH];   // byte address = buf<<16 | ab<<15 | half<<14 | row*128 + slot*16
   const int t = threadIdx.x, lane = t & 63;
+#ifdef CDDMSL_TILE_STAMPS
+  const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   p.x += (long)blockIdx.y * p.bx; p.w += (long)blockIdx.y * p.bw; p.y += (long)blockIdx.y * p.by;
   const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wvu >> 2, wc = wvu & 3;
@@ -1863,6 +1873,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
 #ifdef CDDMSL_STAMPS
   st_last = __builtin_readcyclecounter();
 #endif
+#ifdef CDDMSL_TILE_STAMPS
+  const unsigned long long ts_loop = __builtin_amdgcn_s_memrealtime();
+#endif
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int d = kt & 1;
@@ -1900,6 +1913,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     CDDMSL_PHASE_SYNC_OUT(1, 0);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two groups (every wave has now passed all reads)
+#ifdef CDDMSL_TILE_STAMPS
+  const unsigned long long ts_epi = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef CDDMSL_STAMPS
   if (p.stamps && lane == 0) {
 #pragma unroll
@@ -1911,14 +1927,18 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
 #undef CDDMSL_PHASE_SYNC_OUT
 #undef CDDMSL_STAMP
 
-  // ---- epilogue: per-wave LDS transpose (32 rows x 64 cols f32 per pass, private 8 KiB region; DS ops of one wave
-  // execute in order, so no barrier is needed); a lane then owns 8 consecutive columns of a row: 16-byte residual / mask
-  // loads and y stores.  All of them are buffer-addressed -- rows past M fall outside num_records (loads give 0, stores
-  // are dropped), an absent residual / mask is a zero-sized buffer, per-lane offsets are computed once and the row / pass
-  // position is the wave-uniform soffset -- so the passes are straight-line code without per-row exec masks, zero fills or
-  // 64-bit address arithmetic (together ~half of the old epilogue's vector instructions).
+  // ---- epilogue: per-wave LDS transpose (32 rows x 64 cols f32 per pass; DS ops of one wave execute in order, so no barrier
+  // is needed); a lane then owns 8 consecutive columns of a row: 16-byte residual / mask loads and y stores.  All of them are
+  // buffer-addressed -- rows past M fall outside num_records (loads give 0, stores are dropped), an absent residual / mask is
+  // a zero-sized buffer, per-lane offsets are computed once and the row / pass position is the wave-uniform soffset -- so the
+  // passes are straight-line code without per-row exec masks, zero fills or 64-bit address arithmetic.
+  // The transposition is double-buffered in the wave's private 16 KiB of the (now idle) operand ring: pass a+1's 32 scratch
+  // writes are issued right behind pass a's 8 scratch reads (all four rows at once), so the write drain and the read latency
+  // are each paid once per pass and overlap the arithmetic and stores of the pass before -- tools/tile_stamps.py measured the
+  // former row-at-a-time form (read two chunks, wait, compute, store, scheduling barrier) at 7.4 us per tile without and
+  // 11 us with a residual, against ~1 us of vector-ALU work.
   constexpr int ES = Mma<T>::ES;
-  float* ep = (float*)lds + wvu * 2048;
+  float* ep = (float*)lds + wvu * 4096;
   const int cg = lane & 7, rr = lane >> 3;
   const int n = n0 + wc * 64 + cg * 8;
   float sc[8], bi[8];
@@ -1927,7 +1947,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     sc[j] = p.scale ? p.scale[n + j] : 1.f;
     bi[j] = p.bias ? p.bias[n + j] : 0.f;
   }
-  const bool f32out = ES == 4 || p.out_f32 != 0;
+  const bool has_res = EPI < 0 ? p.residual != nullptr : (EPI & 1) != 0;
+  const bool has_msk = EPI < 0 ? p.relu_mask != nullptr : (EPI & 2) != 0;
+  const bool f32out = EPI < 0 && (ES == 4 || p.out_f32 != 0);
   const int eso = f32out ? 4 : 2;
   const float relu_floor = p.relu ? 0.f : -__builtin_inff();
   const long rows = p.M - m0;
@@ -1936,7 +1958,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)m0 * ld * es), 0, base ? (int)bytes : 0, 0x00020000);
   };
-  const bool rf32 = ES == 2 && p.res_f32;         // f32 residual rows on the bf16 kernel (the mapper's f32 residual stream)
+  const bool rf32 = EPI < 0 && ES == 2 && p.res_f32;         // f32 residual rows on the bf16 kernel (the mapper's f32 residual stream)
   const int esr = rf32 ? 4 : ES;
   // (pooled residual: addressed from the tensor base -- the pooled pixel of a row is not linear in the row)
   const __amdgpu_buffer_rsrc_t ry = mk(p.y, p.ldy, eso), rmsk = mk(p.relu_mask, p.ldm, ES);
@@ -1953,7 +1975,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   };
   const unsigned vy = (unsigned)(((wr * 128 + rr) * p.ldy + n) * eso);
   const unsigned vr = (unsigned)(((wr * 128 + rr) * p.ldr + n) * esr), vm = (unsigned)(((wr * 128 + rr) * p.ldm + n) * ES);
-  const bool emit8 = ES == 2 && p.y8 != nullptr;
+  const bool emit8 = EPI < 0 && ES == 2 && p.y8 != nullptr;
   const __amdgpu_buffer_rsrc_t ry8 = mk(p.y8, p.ldy, 1);
   const unsigned vy8 = (unsigned)((wr * 128 + rr) * p.ldy + n);
   const float q8s = emit8 && p.q8 ? p.q8[0] : 1.f;
@@ -1974,13 +1996,21 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
 #pragma unroll
       for (int q = 0; q < ES / 2; ++q) {       // (an absent operand is not requested at all: even a zero-sized buffer returns its zeros through the vector memory path)
         if (RPOOL) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, pooled_off(m0 + wr * 128 + a * 32 + rr + 8 * i), q * 16, 0);
-        else if (p.residual && !rf32) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * i) * p.ldr * ES + q * 16, 0);
-        if (p.relu_mask) rmsk_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, (a * 32 + 8 * i) * p.ldm * ES + q * 16, 0);
+        else if (has_res && !rf32) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * i) * p.ldr * ES + q * 16, 0);
+        if (has_msk) rmsk_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, (a * 32 + 8 * i) * p.ldm * ES + q * 16, 0);
       }
   };
   if (DEPTH == 2 && !rf32) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
+  auto put = [&](auto A) {                          // accumulator rows 32a..32a+31 -> transposition buffer a & 1
+    constexpr int a = decltype(A)::value;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 16; ++g)                  // element (row rg + 4hh, col 32b + r32) -> ep[row*64 + ((col>>3 ^ row&7) << 3 | col&7)]
+        *(float*)(wbase[(b << 2) ^ (g & 3)] + ((g & 3) + 8 * (g >> 2)) * 256 + (a & 1) * 8192) = acc[a][b][g];
+  };
+  auto pass = [&](auto A) {
+    constexpr int a = decltype(A)::value;
     if (DEPTH == 1) fetch(a, rresb[0], rmskb[0]);
     if (rf32) {                                   // this pass's 4 rows x 32 B, in the two bf16 register sets taken together
 #pragma unroll
@@ -1989,17 +2019,22 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     }
     u32x4 (*rres_)[ES / 2] = rresb[a % DEPTH];
     u32x4 (*rmsk_)[ES / 2] = rmskb[a % DEPTH];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int g = 0; g < 16; ++g)                  // element (row rg + 4hh, col 32b + r32) -> ep[row*64 + ((col>>3 ^ row&7) << 3 | col&7)]
-        *(float*)(wbase[(b << 2) ^ (g & 3)] + ((g & 3) + 8 * (g >> 2)) * 256) = acc[a][b][g];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this pass's scratch writes have landed
+    f32x4 val[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = rr + 8 * i;
-      const f32x4* src = (const f32x4*)(ep + row * 64 + ((cg ^ (row & 7)) << 3));
-      const f32x4 v0 = src[0], v1 = src[1];
+      const f32x4* src = (const f32x4*)(ep + (a & 1) * 2048 + row * 64 + ((cg ^ (row & 7)) << 3));
+      val[i][0] = src[0]; val[i][1] = src[1];
+    }
+    // (compiler fence: the next pass's float stores must stay behind these f32x4 loads -- type-based alias analysis treats them
+    // as unrelated; they go to the OTHER buffer, but a hoisted store of pass a+2 would not)
+    asm volatile("" ::: "memory");
+    if constexpr (a + 1 < 4) put(std::integral_constant<int, a + 1>{});
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v0 = val[i][0], v1 = val[i][1];
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = affine<T>(v[j], sc[j], bi[j]);
@@ -2019,7 +2054,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
             v[j] += 0.25f * __builtin_bit_cast(f32x4, rres_[i][0])[j]; v[4 + j] += 0.25f * __builtin_bit_cast(f32x4, rres_[i][ES / 2 - 1])[j];
           }
         }
-      } else if (p.residual) {
+      } else if (has_res) {
         if (ES == 2) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(rres_[i][0][j] & 0xffff); v[2 * j + 1] += bf2f(rres_[i][0][j] >> 16); }
@@ -2032,7 +2067,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "s"(relu_floor));   // (fmaxf adds a canonicalising op per element)
-      if (p.relu_mask) {
+      if (has_msk) {
         float mv[8];
         if (ES == 2) {
 #pragma unroll
@@ -2047,37 +2082,51 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
         for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
       }
       const unsigned so = (unsigned)((a * 32 + 8 * i) * p.ldy * eso);
+      // Store-data hazard (observed, gfx950): hipcc may put a vector-ALU write to the FIRST data register of a
+      // buffer_store_dwordx4 ... soffset offen directly behind the store (it did: v_mul_hi_u32 of the next row's pooled-pixel
+      // division), and lanes 12-15 of every 16 then stored that instruction's result instead of the output.  Nothing may
+      // WRITE the data registers for a few cycles: a wait behind every store, and a use of the data behind the wait, which
+      // keeps the registers allocated until then (the rows of a pass are otherwise free to interleave).
       if (emit8) {                                  // the e4m3 copy for the consuming convolution (fp8 configuration)
 #pragma unroll
         for (int j = 0; j < 8; ++j) am8 = fmaxf(am8, fabsf(v[j]));
         const u32x2 o8 = {pack4_e4m3(v[0] * q8s, v[1] * q8s, v[2] * q8s, v[3] * q8s), pack4_e4m3(v[4] * q8s, v[5] * q8s, v[6] * q8s, v[7] * q8s)};
         __builtin_amdgcn_raw_buffer_store_b64(o8, ry8, vy8, (unsigned)((a * 32 + 8 * i) * p.ldy), 0);
+        asm volatile("s_nop 4" ::: "memory");
+        asm volatile("" :: "v"(o8));
       }
       if (f32out) {
         const u32x4 o0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
         const u32x4 o1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
         __builtin_amdgcn_raw_buffer_store_b128(o0, ry, vy, so, 0);
         __builtin_amdgcn_raw_buffer_store_b128(o1, ry, vy, so + 16, 0);
+        asm volatile("s_nop 4" ::: "memory");
+        asm volatile("" :: "v"(o0), "v"(o1));
       } else {
         const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
         __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, 0);
+        asm volatile("s_nop 4" ::: "memory");
+        asm volatile("" :: "v"(o));
       }
-      // Store-data hazard (observed, gfx950): hipcc may put a vector-ALU write to the FIRST data register of a
-      // buffer_store_dwordx4 ... soffset offen directly behind the store (it did: v_mul_hi_u32 of the next row's pooled-pixel
-      // division), and lanes 12-15 of every 16 then stored that instruction's result instead of the output.  Nothing may
-      // follow the store for a few cycles.
-      asm volatile("s_nop 4" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
     }
     if (DEPTH == 2 && a + 2 < 4 && !rf32) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
-    // compiler fence: the next pass's float stores into `ep` must stay behind this pass's f32x4 loads from it (type-based
-    // alias analysis treats them as unrelated; hoisted stores overwrote the last rows of a pass in one instantiation)
-    asm volatile("" ::: "memory");
-  }
+  };
+  put(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 1>{});
+  pass(std::integral_constant<int, 2>{});
+  pass(std::integral_constant<int, 3>{});
   if (emit8 && p.amax8) {                           // (rows past M contribute their bias-only values: an over-estimate at worst)
     am8 = wave_max(am8);
     if (lane == 0) atomicMax(p.amax8 + (blockIdx.x & 63), __float_as_uint(am8));
   }
+#ifdef CDDMSL_TILE_STAMPS
+  if (p.tstamps && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (exit stamp = the wave's stores have left)
+    unsigned long long* o = p.tstamps + ((long)blockIdx.x * 8 + wvu) * 4;
+    o[0] = ts_entry; o[1] = ts_loop; o[2] = ts_epi; o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // Shapes the 256x256 kernel takes: whole 256-column tiles, K-tiles inside one filter tap, vector epilogue, <= 32 taps,
@@ -2100,6 +2149,19 @@ static bool use_gemm256(const ConvArgs& a) {
   return tiles >= 160;
 }
 
+
+// the 256x256 kernel's epilogue variant (template parameter EPI): compile-time operand set for bf16 outputs, run-time flags otherwise
+template <typename T, bool TAPS> void launch256(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  if (sizeof(T) == 4 || a.out_f32 || a.res_f32 || a.y8) { hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, -1>), grid, dim3(512), 0, st, a); return; }
+  switch ((a.residual ? 1 : 0) | (a.relu_mask ? 2 : 0)) {
+    case 0: hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, 0>), grid, dim3(512), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, 1>), grid, dim3(512), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, 2>), grid, dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, 3>), grid, dim3(512), 0, st, a); break;
+  }
+}
+template <> void launch256<float, false>(const ConvArgs& a, dim3 grid, hipStream_t st) { hipLaunchKernelGGL((k_conv_fwd256<float, false, false, -1>), grid, dim3(512), 0, st, a); }
+template <> void launch256<float, true>(const ConvArgs& a, dim3 grid, hipStream_t st) { hipLaunchKernelGGL((k_conv_fwd256<float, true, false, -1>), grid, dim3(512), 0, st, a); }
 
 template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
   int ntn = (a.Cout + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
@@ -2127,12 +2189,10 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
     grid = (long)(a.Cout / 256) * ((a.M + 255) / 256);
     g_last_kernel = 3;
     if (g_plan_only) return CDDMSL_OK;
-    if (a.res_pool)
-      hipLaunchKernelGGL((k_conv_fwd256<T, false, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
-    else if (a.KH == 1 && a.KW == 1 && a.pad == 0)
-      hipLaunchKernelGGL((k_conv_fwd256<T, false>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
-    else
-      hipLaunchKernelGGL((k_conv_fwd256<T, true>), dim3((unsigned)grid, (unsigned)g_batch), dim3(512), 0, st, a);
+    const dim3 g256((unsigned)grid, (unsigned)g_batch);
+    if (a.res_pool) hipLaunchKernelGGL((k_conv_fwd256<T, false, true>), g256, dim3(512), 0, st, a);
+    else if (a.KH == 1 && a.KW == 1 && a.pad == 0) launch256<T, false>(a, g256, st);
+    else launch256<T, true>(a, g256, st);
   } else if (a.pool) { g_last_kernel = 2; if (g_plan_only) return CDDMSL_OK; hipLaunchKernelGGL(k_conv_fwd_reg<T>, dim3((unsigned)grid), dim3(256), 0, st, a); }
   else { g_last_kernel = 1; if (g_plan_only) return CDDMSL_OK; hipLaunchKernelGGL(k_conv_fwd<T>, dim3((unsigned)grid, (unsigned)g_batch), dim3(256), 0, st, a); }
   return launch_status();
@@ -2140,6 +2200,10 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
+#ifdef CDDMSL_TILE_STAMPS
+static unsigned long long* g_tile_stamps = nullptr;
+extern "C" void cddmsl_debug_tile_stamps(unsigned long long* p) { g_tile_stamps = p; }
+#endif
 extern "C" int cddmsl_last_kernel(void) { return g_last_kernel; }
 extern "C" int cddmsl_plan_only(int on) { const int was = g_plan_only; g_plan_only = on; return was; }
 
@@ -2175,6 +2239,9 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
   a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
   a.dcpp = make_fastdiv((unsigned)a.cpp); a.dKW = make_fastdiv((unsigned)KW);
   a.xrs = a.cpp; a.wrs = a.Kc; a.bx = a.bw = a.by = 0;
+#ifdef CDDMSL_TILE_STAMPS
+  a.tstamps = g_tile_stamps;
+#endif
   if (a.M == 0) return CDDMSL_OK;
   if (y8) {       // e4m3 second output: bf16 launches of the 256x256 kernel only (its epilogue writes it)
     if (dtype != 0 || (out_f32 & 1) || ldy != Cout || !use_gemm256(a)) return CDDMSL_ERR_ARG;
@@ -2236,8 +2303,8 @@ extern "C" int cddmsl_conv_fwd_fp8(const void* x, const void* w, void* y, const 
   g_last_kernel = 10;
   if (g_plan_only) return CDDMSL_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (KH == 1 && KW == 1 && pad == 0) hipLaunchKernelGGL((k_conv_fwd256<fp8e4, false>), dim3((unsigned)grid, 1), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((k_conv_fwd256<fp8e4, true>), dim3((unsigned)grid, 1), dim3(512), 0, st, a);
+  if (KH == 1 && KW == 1 && pad == 0) launch256<fp8e4, false>(a, dim3((unsigned)grid, 1), st);
+  else launch256<fp8e4, true>(a, dim3((unsigned)grid, 1), st);
   return launch_status();
 }
 

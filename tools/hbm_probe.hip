@@ -1,0 +1,83 @@
+// What the HBM3E of this MI355X sustains for the access mixes of the step's HBM-bound kernels (MI355X_MICROARCH.md prices
+// them at the 8 TB/s data-sheet figure; this is the figure a perfect streaming kernel reaches on the box, the way
+// tools/clock_probe.hip measures what 100 % MFMA issue is worth).  Plain grid-stride kernels, 16 bytes per lane per access,
+// buffers of 1.5 GiB each (>> the 256 MiB Infinity Cache), 20 timed launches after 3 warm-ups, HIP events:
+//   read      sum of one buffer                         (1 R)
+//   write     fill of one buffer                        (1 W)
+//   copy      y = a                                     (1 R : 1 W)     avgpool / relu_bwd / layout kernels
+//   add       y = a + b                                 (2 R : 1 W)     residual epilogues
+//   expand    y[m][0:4c] = f(a[m][0:c]) + r[m][0:4c]    (1.25 R : 1 W by rows: c in, 4c residual in, 4c out)
+//                                                       the N = 4K 1x1 layers (K = 512 -> N = 2048 with residual)
+// Rates are ALGORITHMIC bytes / time.  build + run:
+//   hipcc --offload-arch=gfx950 -O3 tools/hbm_probe.hip -o /tmp/hbm_probe && /tmp/hbm_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__global__ __launch_bounds__(256) void k_read(const u32x4* a, unsigned* sink, long n) {
+  unsigned s = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { u32x4 v = a[i]; s += v[0] ^ v[1] ^ v[2] ^ v[3]; }
+  if (s == 0x12345u) sink[0] = s;
+}
+__global__ __launch_bounds__(256) void k_write(u32x4* y, long n, unsigned c) {
+  u32x4 v = {c, c + 1, c + 2, c + 3};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = v;
+}
+__global__ __launch_bounds__(256) void k_copy(const u32x4* a, u32x4* y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_add(const u32x4* a, const u32x4* b, u32x4* y, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { u32x4 u = a[i], v = b[i]; y[i] = u + v; }
+}
+// rows of c chunks in, 4c chunks residual in, 4c chunks out (c = 64 chunks of 16 B = 512 bf16 channels)
+__global__ __launch_bounds__(256) void k_expand(const u32x4* a, const u32x4* r, u32x4* y, long rows, int c) {
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+    const u32x4* ar = a + row * c;
+    for (int j = threadIdx.x; j < 4 * c; j += 256) { u32x4 u = ar[j & (c - 1)], v = r[row * 4 * c + j]; y[row * 4 * c + j] = u + v; }
+  }
+}
+
+template <typename F> static float timed(F launch) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) launch();
+  hipEventRecord(e0, 0);
+  for (int i = 0; i < 20; ++i) launch();
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  return ms / 20.f;
+}
+
+int main() {
+  const long bytes = 1536L << 20, n = bytes / 16;
+  u32x4 *a, *b, *y;
+  unsigned* sink;
+  if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess || hipMalloc(&y, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  hipMalloc(&sink, 64);
+  hipMemset(a, 1, bytes); hipMemset(b, 2, bytes); hipMemset(y, 0, bytes);
+  hipDeviceProp_t prop;
+  hipGetDeviceProperties(&prop, 0);
+  printf("# %s, %d CUs; buffers %ld MiB; algorithmic TB/s\n", prop.name, prop.multiProcessorCount, bytes >> 20);
+  for (int per_cu : {4, 8, 16, 32}) {
+    const int grid = prop.multiProcessorCount * per_cu;
+    float t;
+    t = timed([&] { hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, a, sink, n); });
+    printf("blocks/CU %2d  read   %.2f", per_cu, bytes / t / 1e9);
+    t = timed([&] { hipLaunchKernelGGL(k_write, dim3(grid), dim3(256), 0, 0, y, n, 7u); });
+    printf("  write  %.2f", bytes / t / 1e9);
+    t = timed([&] { hipLaunchKernelGGL(k_copy, dim3(grid), dim3(256), 0, 0, a, y, n); });
+    printf("  copy   %.2f", 2.0 * bytes / t / 1e9);
+    t = timed([&] { hipLaunchKernelGGL(k_add, dim3(grid), dim3(256), 0, 0, a, b, y, n); });
+    printf("  add    %.2f", 3.0 * bytes / t / 1e9);
+    const int c = 64;
+    const long rows = n / (4 * c);
+    t = timed([&] { hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, 0, a, b, y, rows, c); });
+    printf("  expand %.2f\n", (double)rows * c * 9 * 16 / t / 1e9);
+  }
+  float t = timed([&] { hipMemcpyAsync(y, a, bytes, hipMemcpyDeviceToDevice, 0); });
+  printf("hipMemcpyAsync D2D copy %.2f\n", 2.0 * bytes / t / 1e9);
+  return 0;
+}
