@@ -1742,26 +1742,38 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + base_a), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * p.wrs * 16), 0, 0x7fffffff, 0x00020000);
   unsigned va[2][2], vinv[2][2], vb[2][2];
+  int iy0[2][2], ix0[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = m0 + i * 128 + h * 64 + (t >> 3);
       const bool vm = m < p.M;
-      int iy0, ix0;
-      const long ro = rowoff(vm ? m : m0, iy0, ix0);
+      const long ro = rowoff(vm ? m : m0, iy0[h][i], ix0[h][i]);
       va[h][i] = (unsigned)(ro - base_a) + cl * 16;
-      unsigned inv = 0;
-      if (TAPS) {
-        for (int ky = 0; ky < p.KH; ++ky)
-          for (int kx = 0; kx < p.KW; ++kx) {
-            const int iy = iy0 + ky, ix = ix0 + kx;
-            if (!(vm && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi)) inv |= 1u << (ky * p.KW + kx);
-          }
-      } else if (!vm) va[h][i] |= 0x80000000u;
-      vinv[h][i] = inv;
+      // rows past M: every tap invalid (TAPS) / bit 31 of the offset (no taps); also parks iy0 outside the image for the loops below
+      if (!vm) { iy0[h][i] = -(1 << 20); if (!TAPS) va[h][i] |= 0x80000000u; }
+      vinv[h][i] = 0;
       vb[h][i] = (unsigned)(((2 * i + (t >> 8)) * 64 + h * 32 + ((t >> 3) & 31)) * p.wrs + cl) * 16;
     }
+  if (TAPS) {
+    // tap (ky, kx) of a row is invalid when its input row OR its input column falls outside the image: one pass over the filter
+    // columns builds the row's column mask, one over the filter rows places it (or an all-ones group) -- KH + KW iterations with
+    // the lane's four rows side by side, where the former KH x KW loop per row took ~4 us of a 3x3 tile's start-up
+    // (tools/tile_stamps.py: 5.0 us from kernel entry to the first operand request, 1.2 us for a 1x1 layer).
+    unsigned xm[2][2] = {{0, 0}, {0, 0}};
+    for (int kx = 0; kx < p.KW; ++kx)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xm[h][i] |= ((unsigned)(ix0[h][i] + kx) >= (unsigned)p.Wi ? 1u : 0u) << kx;
+    const unsigned full = (1u << p.KW) - 1u;
+    for (int ky = 0; ky < p.KH; ++ky)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) vinv[h][i] |= ((unsigned)(iy0[h][i] + ky) >= (unsigned)p.Hi ? full : xm[h][i]) << (ky * p.KW);
+  }
   const int step_col = (p.xrs - (p.cpp - KCH)) * 16;                               // next tap in the same filter row
   const int step_row = ((p.Wi - (p.KW - 1)) * p.xrs - (p.cpp - KCH)) * 16;         // first tap of the next filter row
   int left[2] = {tpt, tpt}, tap[2] = {0, 0}, kxs[2] = {0, 0};
