@@ -1708,18 +1708,27 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 // e4m3 copy, no f32 residual stream) or -1 = decided at run time (every other combination, and the exact-f32 instantiations).
 // With run-time flags every row of a pass is a chain of uniform branches: hipcc then neither interleaves the rows nor counts
 // its vmcnt waits across them -- passes 2 and 3 waited vmcnt(0) for their residual rows, i.e. for the previous pass's stores.
-template <typename T, bool TAPS, bool RPOOL = false, int EPI = -1>
+// PERSIST: one workgroup per CU walks the tiles  first + i * gridDim.x  (the XCD-contiguous order xcd_remap gives the one-tile grid)
+// one after the other -- nothing is carried from tile to tile (tools/tile_stamps.py: ~2.4 us pass between a workgroup's end and
+// its successor's first instruction on the CU, and ~1 us of the start-up is kernel-argument and index arithmetic).
+template <typename T, bool TAPS, bool RPOOL = false, int EPI = -1, bool PERSIST = false>
 __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2 * 2 * 2 * 128 * KCH];   // byte address = buf<<16 | ab<<15 | half<<14 | row*128 + slot*16
-  const int t = threadIdx.x, lane = t & 63;
+  const int t_in = threadIdx.x;
+  p.x += (long)blockIdx.y * p.bx; p.w += (long)blockIdx.y * p.bw; p.y += (long)blockIdx.y * p.by;
+  const int ntn = p.Cout >> 8;
+  const int ntiles = PERSIST ? ntn * ((p.M + 255) >> 8) : 0;
+  int lbid = PERSIST ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : xcd_remap(blockIdx.x, gridDim.x);
+  if (PERSIST && lbid >= ntiles) return;
+  for (;;) {
+  int t = t_in;
+  if (PERSIST) asm volatile("" : "+v"(t));       // per-lane values are recomputed per tile, not carried through the main loop
+  const int lane = t & 63;
 #ifdef CDDMSL_TILE_STAMPS
   const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-  p.x += (long)blockIdx.y * p.bx; p.w += (long)blockIdx.y * p.bw; p.y += (long)blockIdx.y * p.by;
   const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wvu >> 2, wc = wvu & 3;
-  const int ntn = p.Cout >> 8;
-  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = lbid % ntn, tile_m = lbid / ntn;
   const int m0 = tile_m * 256, n0 = tile_n * 256;
   const int cl = (t & 7) ^ ((t >> 4) & 7);      // logical K chunk of this lane's LDS slot (slot ^ ((row>>1)&7))
@@ -2134,11 +2143,16 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   }
 #ifdef CDDMSL_TILE_STAMPS
   if (p.tstamps && lane == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (exit stamp = the wave's stores have left)
-    unsigned long long* o = p.tstamps + ((long)blockIdx.x * 8 + wvu) * 4;
+    if (!PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (exit stamp = the wave's stores have left)
+    unsigned long long* o = p.tstamps + ((long)(PERSIST ? lbid : (int)blockIdx.x) * 8 + wvu) * 4;
     o[0] = ts_entry; o[1] = ts_loop; o[2] = ts_epi; o[3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
+  if (!PERSIST) break;
+  lbid += gridDim.x;
+  if (lbid >= ntiles) break;
+  __builtin_amdgcn_s_barrier();                    // the next tile's operand DMA overwrites the other waves' transposition scratch
+  }
 }
 
 // Shapes the 256x256 kernel takes: whole 256-column tiles, K-tiles inside one filter tap, vector epilogue, <= 32 taps,
@@ -2162,10 +2176,40 @@ static bool use_gemm256(const ConvArgs& a) {
 }
 
 
+// Workgroups of the persistent form of the 256x256 kernel: one per CU (a multiple of 8, dealt round-robin over the XCDs), or 0 = use
+// the one-tile-per-workgroup grid (CDDMSL_PERSIST=0; read per launch, so one process can A/B).
+static int persistent_blocks() {
+  static int ncu = -1;
+  if (ncu < 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    ncu = (n / 8) * 8;
+  }
+  const char* e = getenv("CDDMSL_PERSIST");
+  return (e ? atoi(e) : 1) ? ncu : 0;
+}
+
 // the 256x256 kernel's epilogue variant (template parameter EPI): compile-time operand set for bf16 outputs, run-time flags otherwise
 template <typename T, bool TAPS> void launch256(const ConvArgs& a, dim3 grid, hipStream_t st) {
   if (sizeof(T) == 4 || a.out_f32 || a.res_f32 || a.y8) { hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, -1>), grid, dim3(512), 0, st, a); return; }
-  switch ((a.residual ? 1 : 0) | (a.relu_mask ? 2 : 0)) {
+  const int epi = (a.residual ? 1 : 0) | (a.relu_mask ? 2 : 0);
+  // Persistent form (bf16, no taps) for SHORT reductions only: per shape, two builds in one process, K <= 512 layers gain 4-6 %
+  // (the ~2.4 us between workgroups is 10-20 % of such a tile), K >= 2048 layers lose 2-4 % against the hardware's dynamic
+  // dispatch; in the step k_conv_fwd256 50.9 -> 50.4 ms.
+  if constexpr (std::is_same<T, __bf16>::value && !TAPS) {
+    const int nb = persistent_blocks();
+    const char* emk = getenv("CDDMSL_PERSIST_MAXKT");             // (A/B knob) longest reduction, in K-tiles, that takes the persistent form
+    if (nb > 0 && grid.y == 1 && (int)grid.x > nb && (a.Kc >> 3) <= (emk ? atoi(emk) : 8)) {
+      switch (epi) {
+        case 0: hipLaunchKernelGGL((k_conv_fwd256<T, false, false, 0, true>), dim3(nb), dim3(512), 0, st, a); break;
+        case 1: hipLaunchKernelGGL((k_conv_fwd256<T, false, false, 1, true>), dim3(nb), dim3(512), 0, st, a); break;
+        case 2: hipLaunchKernelGGL((k_conv_fwd256<T, false, false, 2, true>), dim3(nb), dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((k_conv_fwd256<T, false, false, 3, true>), dim3(nb), dim3(512), 0, st, a); break;
+      }
+      return;
+    }
+  }
+  switch (epi) {
     case 0: hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, 0>), grid, dim3(512), 0, st, a); break;
     case 1: hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, 1>), grid, dim3(512), 0, st, a); break;
     case 2: hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, 2>), grid, dim3(512), 0, st, a); break;
