@@ -704,6 +704,9 @@ struct WgradArgs {
   int ldo;            // output row stride in elements (default K)
   int direct;         // 0: f32 atomicAdd (split reductions); 1: plain f32 store; 2: plain T store (single split only)
   long bx, bd, bo;    // batch (gridDim.y) byte strides of x, dy, out
+#ifdef CDDMSL_TILE_STAMPS
+  unsigned long long* tstamps = nullptr;   // diagnostic build only (tools/tile_stamps.py)
+#endif
 };
 
 constexpr int WM = 64;                 // m rows per reduction tile
@@ -1303,6 +1306,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_small(WgradArgs p, int nbatc
 __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2 * 2 * 2 * 64 * 16];   // byte = buf<<16 | ab<<15 | half<<14 | row*256 + slot*16
   const int t = threadIdx.x, lane = t & 63;
+#ifdef CDDMSL_TILE_STAMPS
+  const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
+  unsigned long long ts_loop = ts_entry;
+#endif
   p.x += (long)blockIdx.y * p.bx; p.dy += (long)blockIdx.y * p.bd;
   char* outp = (char*)p.dw + (long)blockIdx.y * p.bo;
   const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1454,6 +1461,9 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
     CDDMSL_WAIT8(fa0)
     if (wn == 1) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
     __builtin_amdgcn_sched_barrier(0);
+#ifdef CDDMSL_TILE_STAMPS
+    ts_loop = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (int kt = 0; kt < nmt; ++kt) {
       const int d = kt & 1;
@@ -1504,6 +1514,9 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
 #undef CDDMSL_PHASE_SYNC_IN
 #undef CDDMSL_PHASE_SYNC_OUT
 
+#ifdef CDDMSL_TILE_STAMPS
+  const unsigned long long ts_epi = __builtin_amdgcn_s_memrealtime();
+#endif
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -1520,15 +1533,15 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
         else Mma<__bf16>::store(outp + o * 2, v);
       }
     }
+#ifdef CDDMSL_TILE_STAMPS
+  if (p.tstamps && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = p.tstamps + ((long)blockIdx.x * 8 + wvu) * 4;
+    o[0] = ts_entry; o[1] = ts_loop; o[2] = ts_epi; o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
-// ------------------------------------------------------------------------------------------------
-// weight_prep: f32 master [Cout][KH][KW][Cin] -> T forward weights (same layout) and T dgrad weights
-// Wd[cin][KH-1-ky][KW-1-kx][cout] = W[cout][ky][kx][cin] * scale[cout]
-// ------------------------------------------------------------------------------------------------
-// Tiles of 32 output channels x 32 input channels of one filter tap go through LDS, so that both layouts are written in
-// runs of 32 consecutive elements (the element-wise version scattered 2-byte dgrad stores Cout*KH*KW elements apart:
-// ~1 ms per step for 38 M weights, ten times its HBM time).
 template <typename T>
 __device__ __forceinline__ void weight_prep_body(const float* w, const float* scale, char* wf, char* wd, int Cout, int KH, int KW, int Cin,
                                                  long first, long stride) {
@@ -2403,6 +2416,9 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   a.M = (int)M; a.cpp = Cin * es / 16; a.Kc = KH * KW * a.cpp; a.K = KH * KW * Cin; a.ncc = Cout * es / 16;
   a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
   a.xrs = a.cpp; a.ldo = a.K; a.direct = 0; a.bx = a.bd = a.bo = 0;
+#ifdef CDDMSL_TILE_STAMPS
+  a.tstamps = g_tile_stamps;
+#endif
   if (a.M == 0) return CDDMSL_OK;
   int cols = 256 / es;
   long tiles = (long)((Cout + cols - 1) / cols) * ((a.K + cols - 1) / cols);
