@@ -9,6 +9,7 @@
 #         (GRBM_GUI_ACTIVE / 8 / duration; rocprofv3 sums the 8 XCDs) of its long dispatches
 #   3. tools/shape_profile.py                                                   -> <tag>_shape_profile.txt
 #   4. tools/clock_probe.hip (in-kernel clock of an MFMA-dense loop)            -> <tag>_clock_probe.txt
+#   5. tools/hbm_probe.hip (what plain streaming kernels sustain on this box)   -> <tag>_hbm_probe.txt
 # usage: bash tools/profile_round.sh r02
 set -e
 TAG=${1:-r02}
@@ -74,7 +75,7 @@ def by_grid(rows, counter, mul):
     return d
 fe, wr = by_grid(fetch, "FETCH_SIZE", 2.0), by_grid(write, "WRITE_SIZE", 1.0)
 with open('$OUT/${TAG}_traffic_by_grid.txt', 'w') as f:
-    f.write("# k_conv_fwd256: fabric-side traffic per dispatch (MB; FETCH_SIZE x2, WRITE_SIZE), dispatches grouped by tile count.\n"
+    f.write("# k_conv_fwd256: fabric-side traffic per dispatch (MB; FETCH_SIZE x2, WRITE_SIZE), dispatches grouped by grid size / 512 (= tile count; the\n# persistent form of the short-reduction layers launches one workgroup per CU: all of those appear under 256).\n"
             "# FETCH_SIZE counts the L2's memory-side requests INCLUDING Infinity-Cache hits (MI355X_MICROARCH.md, HBM): it bounds HBM reads from above.\n"
             "# tiles  dispatches  fetch: min / quartiles / max   write: distinct values\n")
     for t in sorted(fe, key=lambda t: -sum(fe[t])):
@@ -86,4 +87,6 @@ python3 tools/shape_profile.py 16 > $OUT/${TAG}_shape_profile.txt 2> $OUT/shape.
 echo "shape profile done"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value tools/clock_probe.hip -o /tmp/clock_probe 2> /dev/null && /tmp/clock_probe > $OUT/${TAG}_clock_probe.txt
 cat $OUT/${TAG}_clock_probe.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -Wno-unused-result tools/hbm_probe.hip -o /tmp/hbm_probe 2> /dev/null && /tmp/hbm_probe > $OUT/${TAG}_hbm_probe.txt
+cat $OUT/${TAG}_hbm_probe.txt
 head -c 400 $OUT/${TAG}_bench_under_rocprof.json; echo
