@@ -215,6 +215,42 @@ def test_conv_fwd_256_tile_kernel(case, dtype, tol, monkeypatch):
         assert (a - b).abs().max() <= tol * a.abs().max()
 
 
+@pytest.mark.parametrize("flags", [(False, False), (True, False), (False, True), (True, True)])
+def test_conv_fwd_256_persistent_form_is_bit_equal(flags, monkeypatch):
+    """Short reductions (K <= 512, bf16, no taps) with more tiles than CUs run the PERSISTENT form of the 256x256 kernel (one workgroup
+    per CU walking its tiles, CDDMSL_PERSIST=1 = default): every epilogue operand set against ATen fp32, and bit-equal to the
+    one-tile-per-workgroup grid (CDDMSL_PERSIST=0).  1 300 tiles: five tiles per workgroup, a ragged last row panel (M = 83 003) and
+    a ragged last round."""
+    from cddmsl_amd import hip
+    res_on, msk_on = flags
+    N, H, W, Cin, Cout = 1, 83003, 1, 128, 1024
+    dev, dtype = "cuda", torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(31)
+    x = torch.randn(N, H, W, Cin, device=dev, generator=g).to(dtype)
+    w = (torch.randn(Cout, 1, 1, Cin, device=dev, generator=g) * Cin ** -0.5).to(dtype)
+    scale = torch.rand(Cout, device=dev, generator=g) + 0.5
+    bias = torch.randn(Cout, device=dev, generator=g) * 0.1
+    res = torch.randn(N, H, W, Cout, device=dev, generator=g).to(dtype) if res_on else None
+    msk = torch.randn(N, H, W, Cout, device=dev, generator=g).to(dtype) if msk_on else None
+    monkeypatch.setenv("CDDMSL_GEMM256", "2")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CDDMSL_PERSIST", mode)
+        out[mode] = hip.conv_fwd(x, w, scale, bias, res, relu=not msk_on, relu_mask=msk, stride=1, pad=0)
+        assert hip._L().cddmsl_last_kernel() == 3
+    torch.cuda.synchronize()
+    assert torch.equal(out["0"], out["1"])
+    ref = (x.float().view(-1, Cin) @ w.float().view(Cout, Cin).t()) * scale + bias
+    if res_on:
+        ref = ref + res.float().view(-1, Cout)
+    if msk_on:
+        ref = ref * (msk.float().view(-1, Cout) > 0)
+    else:
+        ref = ref.clamp_min(0)
+    err = (out["1"].float().view(-1, Cout) - ref).abs().max() / ref.abs().max()
+    assert err < 2e-2, err
+
+
 @pytest.mark.parametrize("g256", ["0", "2"])
 def test_f32_residual_in_the_bf16_gemm_epilogue(g256, monkeypatch):
     """y (f32) = x (bf16) @ W^T + bias + residual (f32): the mapper's residual stream stays f32 and its add rides in the GEMM
