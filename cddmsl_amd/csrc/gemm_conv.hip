@@ -1911,9 +1911,15 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   const unsigned long long ts_loop = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  for (int kt = 0; kt < nkt; ++kt) {
+  // One K-tile = four phases.  LAST (compile time): the tile's final K-tile, peeled out of the loop -- nothing is left to stage and no
+  // wait is due (it was retired by the K-tile before it, or by the prologue).
+  // (Tried here and measured slower, +1 ms of kernel time per step: starting the epilogue's residual / mask rows on their way from HBM
+  // with one dword load per 128-byte line -- a lane per row -- during this last K-tile.  The epilogue's first pass does wait ~2 us
+  // for its operand rows, but 64 single-line requests per instruction cost the load path more than the wait.)
+  auto ktile = [&](int kt, auto LAST) {
+    constexpr bool last = decltype(LAST)::value;
     const int d = kt & 1;
-    const bool more1 = kt + 1 < nkt, more2 = kt + 2 < nkt;
+    const bool more1 = !last, more2 = !last && kt + 2 < nkt;
     // phase 1
     readB(I0{}, fb0);
     if (more1) stageA(I1{}, d ^ 1);
@@ -1933,7 +1939,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     if (more2) {
       stageB(I0{}, d);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
+    } else if (more1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     CDDMSL_PHASE_SYNC_IN();
@@ -1945,7 +1951,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     CDDMSL_PHASE_SYNC_IN();
     CDDMSL_MMA_QUAD(1, 0, fa1, fb0);
     CDDMSL_PHASE_SYNC_OUT(1, 0);
-  }
+  };
+  for (int kt = 0; kt + 1 < nkt; ++kt) ktile(kt, std::false_type{});
+  ktile(nkt - 1, std::true_type{});
   if (wr == 0) __builtin_amdgcn_s_barrier();     // re-align the two groups (every wave has now passed all reads)
 #ifdef CDDMSL_TILE_STAMPS
   const unsigned long long ts_epi = __builtin_amdgcn_s_memrealtime();
