@@ -704,6 +704,8 @@ struct WgradArgs {
   int ldo;            // output row stride in elements (default K)
   int direct;         // 0: f32 atomicAdd (split reductions); 1: plain f32 store; 2: plain T store (single split only)
   long bx, bd, bo;    // batch (gridDim.y) byte strides of x, dy, out
+  float* ws = nullptr;  // split reductions through a workspace: block (split, tile) stores its accumulators, in fragment order, at
+                        // ws[(split * ntiles + tile) * tile_floats ...]; k_wgrad_reduce sums the splits into dw (see cddmsl_set_workspace)
 #ifdef CDDMSL_TILE_STAMPS
   unsigned long long* tstamps = nullptr;   // diagnostic build only (tools/tile_stamps.py)
 #endif
@@ -1032,6 +1034,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_dma(WgradArgs p) {
   }
 
   const int r = lane & 31, h = lane >> 5;
+  if (p.ws) {          // split reduction through the workspace: 16-byte stores in fragment order, 1 KiB per wave instruction
+    f32x4* dst = (f32x4*)p.ws + ((long)(split * ntn + tile_n) * ntk + tile_k) * (4 * NT * NT * 4 * 64) + (wv * NT * NT * 4) * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = {acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]};
+          dst[((a * NT + b) * 4 + g4) * 64] = v;
+        }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -1518,6 +1533,18 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
   const unsigned long long ts_epi = __builtin_amdgcn_s_memrealtime();
 #endif
   const int r = lane & 31, h = lane >> 5;
+  if (p.ws) {          // split reduction through the workspace (see k_conv_wgrad_dma): 32 x 16 bytes per lane instead of 128 atomics
+    f32x4* dst = (f32x4*)p.ws + ((long)(bid * ntn + tile_n) * ntk + tile_k) * (8 * 32 * 64) + (wvu * 32) * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = {acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]};
+          dst[((a * 2 + b) * 4 + g4) * 64] = v;
+        }
+  } else
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -2396,12 +2423,62 @@ static bool wgrad256_ok(const WgradArgs& a, int batch) {
   // long reductions only: each block ends with 64 Ki scalar atomics, which a short m range cannot amortise
   // (threshold from per-shape A/B inside the training step: 9342 (M 66400, 256 x 2304) and 14112 (M 25088, 512 x 4608) run
   // 1.6x faster here than on the 128x128 kernel, 8300 (M 265600, 512 x 256) and everything below run slower)
-  return (long)(a.Cout / 256) * (a.K / 256) * batch * ((a.M + WM - 1) / WM) >= 9000;
+  const char* et = getenv("CDDMSL_WGRAD256_MIN");               // (A/B knob)
+  return (long)(a.Cout / 256) * (a.K / 256) * batch * ((a.M + WM - 1) / WM) >= (et ? atol(et) : 4000);
 }
 // buffer addressing: lane offset + soffset must stay below 2 GiB inside one block's reduction range
 static bool wgrad256_span_ok(const WgradArgs& a) {
   const long rowb = (long)(a.ldd * 2 > a.xrs * 16 ? a.ldd * 2 : a.xrs * 16);
   return ((long)a.mtiles_per_split * WM + WM + 2L * a.Wi + 2) * rowb + (1L << 20) < (1L << 31);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split reductions of the weight-gradient kernels without atomics.  64 Ki f32 atomics per 256x256 block take 50-68 us whatever
+// the order (tools/tile_stamps.py: 1.3 TB/s of atomic payload chip-wide; 45 % of a layer3 launch of k_wgrad256, ~a third of a
+// k_conv_wgrad_dma launch).  With a workspace registered, every block stores its accumulators as they lie in the registers
+// (fragment order: 1 KiB per wave instruction), and this kernel sums a tile's splits -- one thread per 16-byte slot -- and adds the
+// result, scaled, to dw: plain read-modify-write, nothing else touches dw on the stream meanwhile, and the sum is deterministic.
+// WAVES x FR = waves per block x 16-byte slots per lane: 8 x 32 (k_wgrad256: 256x256 tile), 4 x 16 (k_conv_wgrad_dma, bf16: 128x128).
+// ------------------------------------------------------------------------------------------------
+template <int WAVES, int FR>
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const f32x4* ws, float* dw, const float* scale, int ntn, int ntk, int splits, int Cout, int K, int ldo) {
+  constexpr int SLOTS = WAVES * FR * 64;                      // 16-byte slots per tile
+  constexpr int TN = WAVES == 8 ? 256 : 128;                  // tile edge
+  const int tile = blockIdx.x / (SLOTS / 256), q = (blockIdx.x % (SLOTS / 256)) * 256 + threadIdx.x;
+  const int tile_k = tile % ntk, tile_n = tile / ntk;
+  const long ntiles = (long)ntn * ntk;
+  const f32x4* src = ws + (long)tile * SLOTS + q;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= splits; s += 4) {                            // four loads in flight
+    const f32x4 a = src[(s + 0) * ntiles * SLOTS], b = src[(s + 1) * ntiles * SLOTS], c = src[(s + 2) * ntiles * SLOTS], d = src[(s + 3) * ntiles * SLOTS];
+    sum += (a + b) + (c + d);
+  }
+  for (; s < splits; ++s) sum += src[s * ntiles * SLOTS];
+  const int wv = q / (FR * 64), j = (q / 64) % FR, lane = q & 63, r = lane & 31, h = lane >> 5, g4 = j & 3;
+  int a, b, wn, wk;
+  if (WAVES == 8) { a = j >> 3; b = (j >> 2) & 1; wn = wv >> 2; wk = wv & 3; }
+  else { a = j >> 3; b = (j >> 2) & 1; wn = wv >> 1; wk = wv & 1; }
+  const int n = tile_n * TN + wn * (WAVES == 8 ? 128 : 64) + a * 32 + 8 * g4 + 4 * h;
+  const int k = tile_k * TN + wk * 64 + b * 32 + r;
+  if (k >= K) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n + e < Cout) dw[(long)(n + e) * ldo + k] += sum[e] * (scale ? scale[n + e] : 1.f);
+}
+
+static void* g_ws = nullptr;       // device workspace for split reductions (cddmsl_set_workspace); process-wide: one device per process
+static long g_ws_bytes = 0;
+extern "C" int cddmsl_set_workspace(void* ptr, long bytes) {
+  if (bytes < 0 || (ptr == nullptr && bytes != 0) || ((size_t)ptr & 15)) return CDDMSL_ERR_ARG;
+  g_ws = ptr; g_ws_bytes = bytes;
+  return CDDMSL_OK;
+}
+// whether a split reduction of `blocks` tiles of `tile_floats` goes through the workspace (CDDMSL_WGRAD_WS=0: atomics, for A/B)
+static bool use_workspace(long blocks, long tile_floats) {
+  const char* e = getenv("CDDMSL_WGRAD_WS");
+  if (e && atoi(e) == 0) return false;
+  return g_ws != nullptr && blocks * tile_floats * 4 <= g_ws_bytes;
 }
 
 extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const float* scale, int Nimg, int Hi,
@@ -2488,6 +2565,13 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
     if (wgrad256_span_ok(a)) {
       g_last_kernel = 6;
       if (g_plan_only) return CDDMSL_OK;
+      if (sp > 1 && use_workspace(tiles2 * sp, 65536)) {
+        a.ws = (float*)g_ws;
+        hipLaunchKernelGGL(k_wgrad256, dim3((unsigned)(tiles2 * sp)), dim3(512), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((k_wgrad_reduce<8, 32>), dim3((unsigned)(tiles2 * 64)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)g_ws, dw, scale,
+                           Cout / 256, a.K / 256, (int)sp, Cout, a.K, a.ldo);
+        return launch_status();
+      }
       hipLaunchKernelGGL(k_wgrad256, dim3((unsigned)(tiles2 * sp)), dim3(512), 0, (hipStream_t)stream, a);
       return launch_status();
     }
@@ -2495,7 +2579,12 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
   }
   g_last_kernel = same ? 5 : 4;
   if (g_plan_only) return CDDMSL_OK;
-  if (same) {
+  if (same && dtype == 0 && splits > 1 && use_workspace(grid, 16384)) {
+    a.ws = (float*)g_ws;
+    hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_wgrad_reduce<4, 16>), dim3((unsigned)(tiles * 16)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)g_ws, dw, scale,
+                       (Cout + 127) / 128, (a.K + 127) / 128, (int)splits, Cout, a.K, a.ldo);
+  } else if (same) {
     if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   } else {

@@ -25,6 +25,7 @@ def _L():
         L.cddmsl_plan_only.argtypes = [ci]
         L.cddmsl_conv_fwd.argtypes = [vp] * 7 + [ci] * 16 + [vp]
         L.cddmsl_conv_wgrad.argtypes = [vp] * 4 + [ci] * 12 + [vp]
+        L.cddmsl_set_workspace.argtypes = [vp, c_long]
         L.cddmsl_weight_prep.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_weight_prep_multi.argtypes = [vp, ci, ci, vp]
         L.cddmsl_preprocess.argtypes = [vp, vp] + [ci] * 6 + [vp, vp, ci, ci, vp]
@@ -311,6 +312,20 @@ def linear_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask
     return y.view(M, w.shape[0])
 
 
+_WORKSPACE = {}
+WORKSPACE_BYTES = 288 << 20      # the largest split reduction of the 16 x 800x1333 step needs 258 MiB (1 008 blocks x 256 KiB)
+
+
+def ensure_workspace(device):
+    """Registers (once per device) the scratch the weight-gradient kernels' split reductions go through: see cddmsl_set_workspace."""
+    key = torch.device(device).index or 0
+    if key not in _WORKSPACE:
+        ws = torch.empty(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        check(_L().cddmsl_set_workspace(ptr(ws), ctypes.c_long(ws.numel())), "cddmsl_set_workspace")
+        _WORKSPACE[key] = ws
+    return _WORKSPACE[key]
+
+
 def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None):
     """dW[Cout,KH,KW,Cin] (f32) += scale[n] * sum_m dY[m,n] * im2col(x)[m,k].  x NHWC, dy NHWC."""
     require_cuda(x, dy, scale, out)
@@ -322,6 +337,7 @@ def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None
     if out is None:
         out = torch.zeros(w_shape, device=x.device, dtype=torch.float32)
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(w_shape)
+    ensure_workspace(x.device)
     def launch():
         return _L().cddmsl_conv_wgrad(ptr(x), ptr(dy), ptr(out), ptr(scale), N, H, W, Cin, Cout, KH, KW, stride, pad,
                                       int(pool), Cout, _dt(x), stream_ptr())

@@ -40,6 +40,11 @@ int cddmsl_abi_version(void);
 int cddmsl_conv_fwd(const void* x, const void* w, void* y, const float* scale, const float* bias, const void* residual,
                     const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
                     int pool, int ldy, int ldr, int ldm, int relu, int out_f32, int dtype, void* stream);
+/* Device scratch for the weight-gradient kernels' split reductions (no counterpart in the reference: ATen's conv backward owns its
+ * workspace, aten/src/ATen/native/cudnn).  With `bytes` of 16-byte-aligned device memory registered, a split reduction stores its
+ * partial tiles there and a second kernel sums them into dW (deterministic; f32 atomics otherwise, and whenever the launch needs more
+ * than `bytes`).  One workspace per process; launches that use it must be stream-ordered.  (nullptr, 0) unregisters. */
+int cddmsl_set_workspace(void* ptr, long bytes);
 /* dW[n][k] (f32, accumulated) += scale[n] * sum_m dY[m][n] * im2col(x)[m][k] */
 int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const float* scale, int Nimg, int Hi, int Wi, int Cin,
                       int Cout, int KH, int KW, int stride, int pad, int pool, int ldd, int dtype, void* stream);

@@ -371,6 +371,40 @@ def test_conv_wgrad_256_tile_kernel(case, monkeypatch):
     assert (out["0"] - out["2"]).abs().max() <= 1e-4 * ref.abs().max()
 
 
+@pytest.mark.parametrize("g256", ["0", "2"])
+@pytest.mark.parametrize("case", [(8, 28, 28, 256, 256, 3, 1), (4, 40, 37, 128, 512, 1, 0), (9, 14, 14, 512, 512, 3, 1)])
+def test_conv_wgrad_split_reduction_through_workspace(case, g256, monkeypatch):
+    """Split reductions of both bf16 weight-gradient kernels through the registered workspace (partial tiles + k_wgrad_reduce, the
+    default) against f32 atomics (CDDMSL_WGRAD_WS=0) and ATen fp32, accumulating INTO a non-zero dW as the training step does;
+    the workspace form is deterministic: two runs are bit-equal."""
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout, K, p = case
+    dtype = torch.bfloat16
+    x = _rand((N, Cin, H, W), 41).to(dtype).float()
+    dy = _rand((N, Cout, H, W), 42).to(dtype).float()
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(43)) + 0.5
+    w = torch.zeros(Cout, Cin, K, K, requires_grad=True)
+    (F.conv2d(x, w, padding=p) * scale.view(1, -1, 1, 1)).backward(dy)
+    base = _rand((Cout, K, K, Cin), 44)
+    dev = "cuda"
+    xg, dyg = _nhwc(x).to(dev, dtype), _nhwc(dy).to(dev, dtype)
+    monkeypatch.setenv("CDDMSL_GEMM256", g256)
+    out = {}
+    for mode in ("0", "1", "1b"):
+        monkeypatch.setenv("CDDMSL_WGRAD_WS", mode[0])
+        dw = base.to(dev).clone()
+        hip.conv_wgrad(xg, dyg, (Cout, K, K, Cin), scale.to(dev), stride=1, pad=p, out=dw)
+        torch.cuda.synchronize()
+        out[mode] = dw.cpu()
+    assert hip._L().cddmsl_last_kernel() == (6 if g256 == "2" and Cout % 256 == 0 and (K * K * Cin) % 256 == 0 else 5)
+    ref = base + w.grad.permute(0, 2, 3, 1)
+    for mode in ("0", "1"):
+        err = (out[mode] - ref).abs().max() / ref.abs().max()
+        assert err < 2e-2, (mode, float(err))
+    assert (out["0"] - out["1"]).abs().max() <= 1e-4 * ref.abs().max()
+    assert torch.equal(out["1"], out["1b"])
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("case", [(2, 37, 53, 3, 32, 2), (1, 40, 61, 32, 32, 1), (3, 21, 30, 32, 64, 1), (1, 5, 7, 3, 64, 1)])
 def test_conv3x3_small_channel_streaming_kernel(case, dtype, tol):
