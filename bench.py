@@ -180,7 +180,7 @@ def main():
         tr.run_step()
     if args.warmup > 0:
         full = hip.PROFILE.collect()
-    gemm_names = ("k_conv_fwd256", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma") if args.dtype != "fp8" else ("k_conv_fwd256_fp8",)
+    gemm_names = ("k_conv_fwd256", "k_conv_fwd2", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma") if args.dtype != "fp8" else ("k_conv_fwd256_fp8",)
     dom_name = "k_conv_fwd256"
     if full:
         rows = [k for k in gemm_names if k in full]

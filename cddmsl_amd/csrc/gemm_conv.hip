@@ -1744,6 +1744,208 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)l, 16, (int)voff, (int)soff, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Epilogue of a wave's 128 x 64 accumulator tile (acc[4][2] of 32x32 blocks; rows m0 + 128 wr ..., columns n0 + 64 wc ...), shared by
+// the 256x256 kernel and the 256x128 two-workgroup kernel.
+// Per-wave LDS transpose (32 rows x 64 cols f32 per pass; DS ops of one wave execute in order, so no barrier
+// is needed); a lane then owns 8 consecutive columns of a row: 16-byte residual / mask loads and y stores.  All of them are
+// buffer-addressed -- rows past M fall outside num_records (loads give 0, stores are dropped), an absent residual / mask is
+// a zero-sized buffer, per-lane offsets are computed once and the row / pass position is the wave-uniform soffset -- so the
+// passes are straight-line code without per-row exec masks, zero fills or 64-bit address arithmetic.
+// The transposition is double-buffered in the wave's private 16 KiB of the (now idle) operand ring: pass a+1's 32 scratch
+// writes are issued right behind pass a's 8 scratch reads (all four rows at once), so the write drain and the read latency
+// are each paid once per pass and overlap the arithmetic and stores of the pass before -- tools/tile_stamps.py measured the
+// former row-at-a-time form (read two chunks, wait, compute, store, scheduling barrier) at 7.4 us per tile without and
+// 11 us with a residual, against ~1 us of vector-ALU work.
+// `ep`: 16 KiB of LDS private to the wave.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool RPOOL, int EPI>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4][2], float* ep, int wr, int wc, int lane, int m0, int n0) {
+  constexpr int ES = Mma<T>::ES;
+  const int r32 = lane & 31, hh = lane >> 5;
+  const int cg = lane & 7, rr = lane >> 3;
+  const int n = n0 + wc * 64 + cg * 8;
+  float sc[8], bi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = p.scale ? p.scale[n + j] : 1.f;
+    bi[j] = p.bias ? p.bias[n + j] : 0.f;
+  }
+  const bool has_res = EPI < 0 ? p.residual != nullptr : (EPI & 1) != 0;
+  const bool has_msk = EPI < 0 ? p.relu_mask != nullptr : (EPI & 2) != 0;
+  const bool f32out = EPI < 0 && (ES == 4 || p.out_f32 != 0);
+  const int eso = f32out ? 4 : 2;
+  const float relu_floor = p.relu ? 0.f : -__builtin_inff();
+  const long rows = p.M - m0;
+  auto mk = [&](const char* base, long ld, int es) {
+    long bytes = rows * ld * es;
+    if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)m0 * ld * es), 0, base ? (int)bytes : 0, 0x00020000);
+  };
+  const bool rf32 = EPI < 0 && ES == 2 && p.res_f32;         // f32 residual rows on the bf16 kernel (the mapper's f32 residual stream)
+  const int esr = rf32 ? 4 : ES;
+  // (pooled residual: addressed from the tensor base -- the pooled pixel of a row is not linear in the row)
+  const __amdgpu_buffer_rsrc_t ry = mk(p.y, p.ldy, eso), rmsk = mk(p.relu_mask, p.ldm, ES);
+  // RPOOL is a template parameter, not a run-time branch: with the pooled path compiled into the one kernel every launch
+  // ran 5 % slower (more uniform branches per epilogue row), although three launches per step use it.
+  const __amdgpu_buffer_rsrc_t rres = RPOOL ? __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, 0x7fffffff, 0x00020000)
+                                            : mk(p.residual, p.ldr, esr);
+  auto pooled_off = [&](int m) -> unsigned {      // byte offset of this lane's 8 columns in the pooled row of output pixel m
+    const unsigned tq = fdiv((unsigned)m, p.dWo), ox = m - tq * p.Wo;
+    const unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
+    const unsigned hp = p.Ho >> 1, wp = p.Wo >> 1;
+    const bool in = m < p.M && (oy >> 1) < hp && (ox >> 1) < wp;      // an odd size's last row / column has no pooled pixel
+    return in ? (unsigned)((((img * hp + (oy >> 1)) * wp + (ox >> 1)) * (unsigned)p.ldr + (unsigned)n) * ES) : 0x80000000u;
+  };
+  const unsigned vy = (unsigned)(((wr * 128 + rr) * p.ldy + n) * eso);
+  const unsigned vr = (unsigned)(((wr * 128 + rr) * p.ldr + n) * esr), vm = (unsigned)(((wr * 128 + rr) * p.ldm + n) * ES);
+  const bool emit8 = EPI < 0 && ES == 2 && p.y8 != nullptr;
+  const __amdgpu_buffer_rsrc_t ry8 = mk(p.y8, p.ldy, 1);
+  const unsigned vy8 = (unsigned)((wr * 128 + rr) * p.ldy + n);
+  const float q8s = emit8 && p.q8 ? p.q8[0] : 1.f;
+  float am8 = 0.f;
+  // bf16: residual / mask rows are fetched TWO passes ahead (two register sets, static indices): with one block per CU
+  // nothing else hides their HBM latency.  The f32 parity instantiation (twice the registers per row) one pass ahead.
+  constexpr int DEPTH = ES == 2 ? 2 : 1;
+  // transposition writes: the swizzled chunk (col>>3) ^ (row&7) splits into a lane part ((r32>>3) ^ (hh<<2)) XOR a
+  // compile-time part ((b<<2) ^ (g&3)): eight per-lane base addresses, the row of a register is an immediate offset
+  char* wbase[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    wbase[c] = (char*)ep + (hh * 4 * 64 + ((((r32 >> 3) ^ (hh << 2)) ^ c) << 3) + (r32 & 7)) * 4;
+  u32x4 rresb[DEPTH][4][ES / 2], rmskb[DEPTH][4][ES / 2];
+  auto fetch = [&](int a, u32x4 (*rres_)[ES / 2], u32x4 (*rmsk_)[ES / 2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < ES / 2; ++q) {       // (an absent operand is not requested at all: even a zero-sized buffer returns its zeros through the vector memory path)
+        if (RPOOL) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, pooled_off(m0 + wr * 128 + a * 32 + rr + 8 * i), q * 16, 0);
+        else if (has_res && !rf32) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * i) * p.ldr * ES + q * 16, 0);
+        if (has_msk) rmsk_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, (a * 32 + 8 * i) * p.ldm * ES + q * 16, 0);
+      }
+  };
+  if (DEPTH == 2 && !rf32) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
+  auto put = [&](auto A) {                          // accumulator rows 32a..32a+31 -> transposition buffer a & 1
+    constexpr int a = decltype(A)::value;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 16; ++g)                  // element (row rg + 4hh, col 32b + r32) -> ep[row*64 + ((col>>3 ^ row&7) << 3 | col&7)]
+        *(float*)(wbase[(b << 2) ^ (g & 3)] + ((g & 3) + 8 * (g >> 2)) * 256 + (a & 1) * 8192) = acc[a][b][g];
+  };
+  auto pass = [&](auto A) {
+    constexpr int a = decltype(A)::value;
+    if (DEPTH == 1) fetch(a, rresb[0], rmskb[0]);
+    if (rf32) {                                   // this pass's 4 rows x 32 B, in the two bf16 register sets taken together
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        rresb[(f >> 2) % DEPTH][f & 3][0] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * (f >> 1)) * p.ldr * 4 + (f & 1) * 16, 0);
+    }
+    u32x4 (*rres_)[ES / 2] = rresb[a % DEPTH];
+    u32x4 (*rmsk_)[ES / 2] = rmskb[a % DEPTH];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this pass's scratch writes have landed
+    f32x4 val[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rr + 8 * i;
+      const f32x4* src = (const f32x4*)(ep + (a & 1) * 2048 + row * 64 + ((cg ^ (row & 7)) << 3));
+      val[i][0] = src[0]; val[i][1] = src[1];
+    }
+    // (compiler fence: the next pass's float stores must stay behind these f32x4 loads -- type-based alias analysis treats them
+    // as unrelated; they go to the OTHER buffer, but a hoisted store of pass a+2 would not)
+    asm volatile("" ::: "memory");
+    if constexpr (a + 1 < 4) put(std::integral_constant<int, a + 1>{});
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 v0 = val[i][0], v1 = val[i][1];
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = affine<T>(v[j], sc[j], bi[j]);
+      if (rf32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] += __builtin_bit_cast(f32x4, rresb[((2 * i) >> 2) % DEPTH][(2 * i) & 3][0])[j];
+          v[4 + j] += __builtin_bit_cast(f32x4, rresb[((2 * i + 1) >> 2) % DEPTH][(2 * i + 1) & 3][0])[j];
+        }
+      } else if (RPOOL) {                         // (x 0.25 is exact: the same value avgpool2_bwd would have stored)
+        if (ES == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[2 * j] += 0.25f * bf2f(rres_[i][0][j] & 0xffff); v[2 * j + 1] += 0.25f * bf2f(rres_[i][0][j] >> 16); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] += 0.25f * __builtin_bit_cast(f32x4, rres_[i][0])[j]; v[4 + j] += 0.25f * __builtin_bit_cast(f32x4, rres_[i][ES / 2 - 1])[j];
+          }
+        }
+      } else if (has_res) {
+        if (ES == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(rres_[i][0][j] & 0xffff); v[2 * j + 1] += bf2f(rres_[i][0][j] >> 16); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] += __builtin_bit_cast(f32x4, rres_[i][0])[j]; v[4 + j] += __builtin_bit_cast(f32x4, rres_[i][ES / 2 - 1])[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "s"(relu_floor));   // (fmaxf adds a canonicalising op per element)
+      if (has_msk) {
+        float mv[8];
+        if (ES == 2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { mv[2 * j] = bf2f(rmsk_[i][0][j] & 0xffff); mv[2 * j + 1] = bf2f(rmsk_[i][0][j] >> 16); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            mv[j] = __builtin_bit_cast(f32x4, rmsk_[i][0])[j]; mv[4 + j] = __builtin_bit_cast(f32x4, rmsk_[i][ES / 2 - 1])[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
+      }
+      const unsigned so = (unsigned)((a * 32 + 8 * i) * p.ldy * eso);
+      // Store-data hazard (observed, gfx950): hipcc may put a vector-ALU write to the FIRST data register of a
+      // buffer_store_dwordx4 ... soffset offen directly behind the store (it did: v_mul_hi_u32 of the next row's pooled-pixel
+      // division), and lanes 12-15 of every 16 then stored that instruction's result instead of the output.  Nothing may
+      // WRITE the data registers for a few cycles: a wait behind every store, and a use of the data behind the wait, which
+      // keeps the registers allocated until then (the rows of a pass are otherwise free to interleave).
+      if (emit8) {                                  // the e4m3 copy for the consuming convolution (fp8 configuration)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) am8 = fmaxf(am8, fabsf(v[j]));
+        const u32x2 o8 = {pack4_e4m3(v[0] * q8s, v[1] * q8s, v[2] * q8s, v[3] * q8s), pack4_e4m3(v[4] * q8s, v[5] * q8s, v[6] * q8s, v[7] * q8s)};
+        __builtin_amdgcn_raw_buffer_store_b64(o8, ry8, vy8, (unsigned)((a * 32 + 8 * i) * p.ldy), 0);
+        asm volatile("s_nop 4" ::: "memory");
+        asm volatile("" :: "v"(o8));
+      }
+      if (f32out) {
+        const u32x4 o0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
+        const u32x4 o1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(o0, ry, vy, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, ry, vy, so + 16, 0);
+        asm volatile("s_nop 4" ::: "memory");
+        asm volatile("" :: "v"(o0), "v"(o1));
+      } else {
+        const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, 0);
+        asm volatile("s_nop 4" ::: "memory");
+        asm volatile("" :: "v"(o));
+      }
+    }
+    if (DEPTH == 2 && a + 2 < 4 && !rf32) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
+  };
+  put(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 1>{});
+  pass(std::integral_constant<int, 2>{});
+  pass(std::integral_constant<int, 3>{});
+  if (emit8 && p.amax8) {                           // (rows past M contribute their bias-only values: an over-estimate at worst)
+    am8 = wave_max(am8);
+    if (lane == 0) atomicMax(p.amax8 + (blockIdx.x & 63), __float_as_uint(am8));
+  }
+}
+
 // EPI: which optional epilogue operands exist, as a COMPILE-TIME fact (bit 0 residual rows, bit 1 ReLU-mask rows; bf16 output, no
 // e4m3 copy, no f32 residual stream) or -1 = decided at run time (every other combination, and the exact-f32 instantiations).
 // With run-time flags every row of a pass is a chain of uniform branches: hipcc then neither interleaves the rows nor counts
@@ -1996,199 +2198,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
 #undef CDDMSL_PHASE_SYNC_OUT
 #undef CDDMSL_STAMP
 
-  // ---- epilogue: per-wave LDS transpose (32 rows x 64 cols f32 per pass; DS ops of one wave execute in order, so no barrier
-  // is needed); a lane then owns 8 consecutive columns of a row: 16-byte residual / mask loads and y stores.  All of them are
-  // buffer-addressed -- rows past M fall outside num_records (loads give 0, stores are dropped), an absent residual / mask is
-  // a zero-sized buffer, per-lane offsets are computed once and the row / pass position is the wave-uniform soffset -- so the
-  // passes are straight-line code without per-row exec masks, zero fills or 64-bit address arithmetic.
-  // The transposition is double-buffered in the wave's private 16 KiB of the (now idle) operand ring: pass a+1's 32 scratch
-  // writes are issued right behind pass a's 8 scratch reads (all four rows at once), so the write drain and the read latency
-  // are each paid once per pass and overlap the arithmetic and stores of the pass before -- tools/tile_stamps.py measured the
-  // former row-at-a-time form (read two chunks, wait, compute, store, scheduling barrier) at 7.4 us per tile without and
-  // 11 us with a residual, against ~1 us of vector-ALU work.
-  constexpr int ES = Mma<T>::ES;
-  float* ep = (float*)lds + wvu * 4096;
-  const int cg = lane & 7, rr = lane >> 3;
-  const int n = n0 + wc * 64 + cg * 8;
-  float sc[8], bi[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sc[j] = p.scale ? p.scale[n + j] : 1.f;
-    bi[j] = p.bias ? p.bias[n + j] : 0.f;
-  }
-  const bool has_res = EPI < 0 ? p.residual != nullptr : (EPI & 1) != 0;
-  const bool has_msk = EPI < 0 ? p.relu_mask != nullptr : (EPI & 2) != 0;
-  const bool f32out = EPI < 0 && (ES == 4 || p.out_f32 != 0);
-  const int eso = f32out ? 4 : 2;
-  const float relu_floor = p.relu ? 0.f : -__builtin_inff();
-  const long rows = p.M - m0;
-  auto mk = [&](const char* base, long ld, int es) {
-    long bytes = rows * ld * es;
-    if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)m0 * ld * es), 0, base ? (int)bytes : 0, 0x00020000);
-  };
-  const bool rf32 = EPI < 0 && ES == 2 && p.res_f32;         // f32 residual rows on the bf16 kernel (the mapper's f32 residual stream)
-  const int esr = rf32 ? 4 : ES;
-  // (pooled residual: addressed from the tensor base -- the pooled pixel of a row is not linear in the row)
-  const __amdgpu_buffer_rsrc_t ry = mk(p.y, p.ldy, eso), rmsk = mk(p.relu_mask, p.ldm, ES);
-  // RPOOL is a template parameter, not a run-time branch: with the pooled path compiled into the one kernel every launch
-  // ran 5 % slower (more uniform branches per epilogue row), although three launches per step use it.
-  const __amdgpu_buffer_rsrc_t rres = RPOOL ? __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, 0x7fffffff, 0x00020000)
-                                            : mk(p.residual, p.ldr, esr);
-  auto pooled_off = [&](int m) -> unsigned {      // byte offset of this lane's 8 columns in the pooled row of output pixel m
-    const unsigned tq = fdiv((unsigned)m, p.dWo), ox = m - tq * p.Wo;
-    const unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
-    const unsigned hp = p.Ho >> 1, wp = p.Wo >> 1;
-    const bool in = m < p.M && (oy >> 1) < hp && (ox >> 1) < wp;      // an odd size's last row / column has no pooled pixel
-    return in ? (unsigned)((((img * hp + (oy >> 1)) * wp + (ox >> 1)) * (unsigned)p.ldr + (unsigned)n) * ES) : 0x80000000u;
-  };
-  const unsigned vy = (unsigned)(((wr * 128 + rr) * p.ldy + n) * eso);
-  const unsigned vr = (unsigned)(((wr * 128 + rr) * p.ldr + n) * esr), vm = (unsigned)(((wr * 128 + rr) * p.ldm + n) * ES);
-  const bool emit8 = EPI < 0 && ES == 2 && p.y8 != nullptr;
-  const __amdgpu_buffer_rsrc_t ry8 = mk(p.y8, p.ldy, 1);
-  const unsigned vy8 = (unsigned)((wr * 128 + rr) * p.ldy + n);
-  const float q8s = emit8 && p.q8 ? p.q8[0] : 1.f;
-  float am8 = 0.f;
-  // bf16: residual / mask rows are fetched TWO passes ahead (two register sets, static indices): with one block per CU
-  // nothing else hides their HBM latency.  The f32 parity instantiation (twice the registers per row) one pass ahead.
-  constexpr int DEPTH = ES == 2 ? 2 : 1;
-  // transposition writes: the swizzled chunk (col>>3) ^ (row&7) splits into a lane part ((r32>>3) ^ (hh<<2)) XOR a
-  // compile-time part ((b<<2) ^ (g&3)): eight per-lane base addresses, the row of a register is an immediate offset
-  char* wbase[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-    wbase[c] = (char*)ep + (hh * 4 * 64 + ((((r32 >> 3) ^ (hh << 2)) ^ c) << 3) + (r32 & 7)) * 4;
-  u32x4 rresb[DEPTH][4][ES / 2], rmskb[DEPTH][4][ES / 2];
-  auto fetch = [&](int a, u32x4 (*rres_)[ES / 2], u32x4 (*rmsk_)[ES / 2]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int q = 0; q < ES / 2; ++q) {       // (an absent operand is not requested at all: even a zero-sized buffer returns its zeros through the vector memory path)
-        if (RPOOL) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, pooled_off(m0 + wr * 128 + a * 32 + rr + 8 * i), q * 16, 0);
-        else if (has_res && !rf32) rres_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * i) * p.ldr * ES + q * 16, 0);
-        if (has_msk) rmsk_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, (a * 32 + 8 * i) * p.ldm * ES + q * 16, 0);
-      }
-  };
-  if (DEPTH == 2 && !rf32) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
-  auto put = [&](auto A) {                          // accumulator rows 32a..32a+31 -> transposition buffer a & 1
-    constexpr int a = decltype(A)::value;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int g = 0; g < 16; ++g)                  // element (row rg + 4hh, col 32b + r32) -> ep[row*64 + ((col>>3 ^ row&7) << 3 | col&7)]
-        *(float*)(wbase[(b << 2) ^ (g & 3)] + ((g & 3) + 8 * (g >> 2)) * 256 + (a & 1) * 8192) = acc[a][b][g];
-  };
-  auto pass = [&](auto A) {
-    constexpr int a = decltype(A)::value;
-    if (DEPTH == 1) fetch(a, rresb[0], rmskb[0]);
-    if (rf32) {                                   // this pass's 4 rows x 32 B, in the two bf16 register sets taken together
-#pragma unroll
-      for (int f = 0; f < 8; ++f)
-        rresb[(f >> 2) % DEPTH][f & 3][0] = __builtin_amdgcn_raw_buffer_load_b128(rres, vr, (a * 32 + 8 * (f >> 1)) * p.ldr * 4 + (f & 1) * 16, 0);
-    }
-    u32x4 (*rres_)[ES / 2] = rresb[a % DEPTH];
-    u32x4 (*rmsk_)[ES / 2] = rmskb[a % DEPTH];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this pass's scratch writes have landed
-    f32x4 val[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = rr + 8 * i;
-      const f32x4* src = (const f32x4*)(ep + (a & 1) * 2048 + row * 64 + ((cg ^ (row & 7)) << 3));
-      val[i][0] = src[0]; val[i][1] = src[1];
-    }
-    // (compiler fence: the next pass's float stores must stay behind these f32x4 loads -- type-based alias analysis treats them
-    // as unrelated; they go to the OTHER buffer, but a hoisted store of pass a+2 would not)
-    asm volatile("" ::: "memory");
-    if constexpr (a + 1 < 4) put(std::integral_constant<int, a + 1>{});
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 v0 = val[i][0], v1 = val[i][1];
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = affine<T>(v[j], sc[j], bi[j]);
-      if (rf32) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] += __builtin_bit_cast(f32x4, rresb[((2 * i) >> 2) % DEPTH][(2 * i) & 3][0])[j];
-          v[4 + j] += __builtin_bit_cast(f32x4, rresb[((2 * i + 1) >> 2) % DEPTH][(2 * i + 1) & 3][0])[j];
-        }
-      } else if (RPOOL) {                         // (x 0.25 is exact: the same value avgpool2_bwd would have stored)
-        if (ES == 2) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[2 * j] += 0.25f * bf2f(rres_[i][0][j] & 0xffff); v[2 * j + 1] += 0.25f * bf2f(rres_[i][0][j] >> 16); }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] += 0.25f * __builtin_bit_cast(f32x4, rres_[i][0])[j]; v[4 + j] += 0.25f * __builtin_bit_cast(f32x4, rres_[i][ES / 2 - 1])[j];
-          }
-        }
-      } else if (has_res) {
-        if (ES == 2) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { v[2 * j] += bf2f(rres_[i][0][j] & 0xffff); v[2 * j + 1] += bf2f(rres_[i][0][j] >> 16); }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            v[j] += __builtin_bit_cast(f32x4, rres_[i][0])[j]; v[4 + j] += __builtin_bit_cast(f32x4, rres_[i][ES / 2 - 1])[j];
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "s"(relu_floor));   // (fmaxf adds a canonicalising op per element)
-      if (has_msk) {
-        float mv[8];
-        if (ES == 2) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { mv[2 * j] = bf2f(rmsk_[i][0][j] & 0xffff); mv[2 * j + 1] = bf2f(rmsk_[i][0][j] >> 16); }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            mv[j] = __builtin_bit_cast(f32x4, rmsk_[i][0])[j]; mv[4 + j] = __builtin_bit_cast(f32x4, rmsk_[i][ES / 2 - 1])[j];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (!(mv[j] > 0.f)) v[j] = 0.f;
-      }
-      const unsigned so = (unsigned)((a * 32 + 8 * i) * p.ldy * eso);
-      // Store-data hazard (observed, gfx950): hipcc may put a vector-ALU write to the FIRST data register of a
-      // buffer_store_dwordx4 ... soffset offen directly behind the store (it did: v_mul_hi_u32 of the next row's pooled-pixel
-      // division), and lanes 12-15 of every 16 then stored that instruction's result instead of the output.  Nothing may
-      // WRITE the data registers for a few cycles: a wait behind every store, and a use of the data behind the wait, which
-      // keeps the registers allocated until then (the rows of a pass are otherwise free to interleave).
-      if (emit8) {                                  // the e4m3 copy for the consuming convolution (fp8 configuration)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) am8 = fmaxf(am8, fabsf(v[j]));
-        const u32x2 o8 = {pack4_e4m3(v[0] * q8s, v[1] * q8s, v[2] * q8s, v[3] * q8s), pack4_e4m3(v[4] * q8s, v[5] * q8s, v[6] * q8s, v[7] * q8s)};
-        __builtin_amdgcn_raw_buffer_store_b64(o8, ry8, vy8, (unsigned)((a * 32 + 8 * i) * p.ldy), 0);
-        asm volatile("s_nop 4" ::: "memory");
-        asm volatile("" :: "v"(o8));
-      }
-      if (f32out) {
-        const u32x4 o0 = {__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])};
-        const u32x4 o1 = {__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(o0, ry, vy, so, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o1, ry, vy, so + 16, 0);
-        asm volatile("s_nop 4" ::: "memory");
-        asm volatile("" :: "v"(o0), "v"(o1));
-      } else {
-        const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, 0);
-        asm volatile("s_nop 4" ::: "memory");
-        asm volatile("" :: "v"(o));
-      }
-    }
-    if (DEPTH == 2 && a + 2 < 4 && !rf32) fetch(a + 2, rresb[a % DEPTH], rmskb[a % DEPTH]);
-  };
-  put(std::integral_constant<int, 0>{});
-  pass(std::integral_constant<int, 0>{});
-  pass(std::integral_constant<int, 1>{});
-  pass(std::integral_constant<int, 2>{});
-  pass(std::integral_constant<int, 3>{});
-  if (emit8 && p.amax8) {                           // (rows past M contribute their bias-only values: an over-estimate at worst)
-    am8 = wave_max(am8);
-    if (lane == 0) atomicMax(p.amax8 + (blockIdx.x & 63), __float_as_uint(am8));
-  }
+  tile_epilogue<T, RPOOL, EPI>(p, acc, (float*)lds + wvu * 4096, wr, wc, lane, m0, n0);
 #ifdef CDDMSL_TILE_STAMPS
   if (p.tstamps && lane == 0) {
     if (!PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (exit stamp = the wave's stores have left)
@@ -2201,6 +2211,171 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   if (lbid >= ntiles) break;
   __builtin_amdgcn_s_barrier();                    // the next tile's operand DMA overwrites the other waves' transposition scratch
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 128 tile, 4 waves (2 x 2; 128 x 64 per wave -- the 256x256 kernel's per-wave tile and operand reuse), TWO workgroups per CU.
+//
+// The 256x256 kernel owns its CU: its tile's start-up (operands' first trip from HBM), main loop and epilogue traffic run one
+// after the other, which leaves the layers whose epilogue moves as many bytes as their main loop takes time at about half of
+// either roofline (tools/tile_stamps.py).  Here two independent workgroups share the CU's matrix pipes and memory path: while
+// one drains its tile the other multiplies.  No ping-pong between wave groups (each SIMD hosts one wave of each workgroup, not
+// synchronised with each other); instead each wave pipelines itself: the LDS reads of K-tile kt+1 (12 x 16 bytes per lane) and
+// the LDS-DMA of K-tile kt+3 are issued in front of K-tile kt's 16 MFMAs, one barrier per K-tile.
+// K-tile = 4 chunks (32 bf16): LDS ring of 3 stages x (256 + 128 rows x 64 B) = 72 KiB per workgroup; 64-byte rows, chunk
+// ^= (row >> 1) & 3 on the source side of the DMA and on the ds_read_b128 side (8 consecutive rows cover the 8 bank groups).
+// One operand stream (all six DMAs of a K-tile share the filter-tap state).  Epilogue: tile_epilogue, scratch = the idle ring.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool TAPS, int EPI>
+__global__ __launch_bounds__(256, 2) void k_conv_fwd2(ConvArgs p) {
+  constexpr int SA = 256 * 64, SB = 128 * 64, SS = SA + SB, STAGES = 3;
+  __shared__ __attribute__((aligned(16))) u32x4 lds[STAGES * SS / 16];
+  const int t = threadIdx.x, lane = t & 63;
+  p.x += (long)blockIdx.y * p.bx; p.w += (long)blockIdx.y * p.bw; p.y += (long)blockIdx.y * p.by;
+  const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wvu >> 1, wc = wvu & 1;
+  const int ntn = p.Cout >> 7;
+  const int lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = lbid % ntn, tile_m = lbid / ntn;
+  const int m0 = tile_m * 256, n0 = tile_n * 128;
+  const int cl = (t & 3) ^ ((t >> 3) & 3);      // logical K chunk of this lane's LDS slot (slot ^ ((row>>1)&3)); rows (t>>2) + 64 i
+  const int nkt = p.Kc >> 2;
+  const int tpt = p.cpp >> 2;                   // K-tiles per filter tap
+
+  auto rowoff = [&](int m, int& iy0, int& ix0) {
+    const unsigned tq = fdiv((unsigned)m, p.dWo), ox = m - tq * p.Wo;
+    const unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
+    iy0 = (int)oy * p.stride - p.pad; ix0 = (int)ox * p.stride - p.pad;
+    return (((long)img * p.Hi + iy0) * p.Wi + ix0) * p.xrs * 16;
+  };
+  int iyb, ixb;
+  const long base_a = rowoff(m0, iyb, ixb);
+  const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + base_a), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * p.wrs * 16), 0, 0x7fffffff, 0x00020000);
+  unsigned va[4], vinv[4], vb[2];
+  int iy0[4], ix0[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + (t >> 2) + 64 * i;
+    const bool vm = m < p.M;
+    const long ro = rowoff(vm ? m : m0, iy0[i], ix0[i]);
+    va[i] = (unsigned)(ro - base_a) + cl * 16;
+    if (!vm) { iy0[i] = -(1 << 20); if (!TAPS) va[i] |= 0x80000000u; }
+    vinv[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) vb[i] = (unsigned)((((t >> 2) + 64 * i) * p.wrs + cl) * 16);
+  if (TAPS) {                                   // (as in k_conv_fwd256: column mask, then one step per filter row)
+    unsigned xm[4] = {0, 0, 0, 0};
+    for (int kx = 0; kx < p.KW; ++kx)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xm[i] |= ((unsigned)(ix0[i] + kx) >= (unsigned)p.Wi ? 1u : 0u) << kx;
+    const unsigned full = (1u << p.KW) - 1u;
+    for (int ky = 0; ky < p.KH; ++ky)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vinv[i] |= ((unsigned)(iy0[i] + ky) >= (unsigned)p.Hi ? full : xm[i]) << (ky * p.KW);
+  }
+  const int step_col = (p.xrs - (p.cpp - 4)) * 16;
+  const int step_row = ((p.Wi - (p.KW - 1)) * p.xrs - (p.cpp - 4)) * 16;
+  int left = tpt, tap = 0, kxs = 0;
+  unsigned soa = 0, sob = 0;
+
+  char* const L = (char*)lds;
+  auto stage = [&](int st) {                    // the next K-tile of the operand stream -> ring stage st
+    char* dst = L + st * SS + wvu * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned v = va[i];
+      if (TAPS) v |= __builtin_amdgcn_ubfe(vinv[i], (unsigned)tap, 1u) << 31;
+      blds16(ra_rsrc, v, soa, dst + i * 4096);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) blds16(rb_rsrc, vb[i], sob, dst + SA + i * 4096);
+    sob += 64;
+    if (TAPS) {
+      int step = 64;
+      if (--left == 0) {
+        left = tpt; ++tap;
+        if (++kxs == p.KW) { kxs = 0; step = step_row; } else step = step_col;
+      }
+      soa += step;
+    } else soa += 64;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int r32 = lane & 31, hh = lane >> 5, sw = (r32 >> 1) & 3;
+  unsigned ada[2], adb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    ada[ks] = (unsigned)(((wr * 128 + r32) * 4 + ((2 * ks + hh) ^ sw)) * 16);
+    adb[ks] = (unsigned)(SA + ((wc * 64 + r32) * 4 + ((2 * ks + hh) ^ sw)) * 16);
+  }
+  u32x4 fa[2][4][2], fb[2][2][2];               // [register set][32-row / 32-column tile][k-step]
+  auto readf = [&](auto SET, int st) {
+    constexpr int set = decltype(SET)::value;
+    const char* base = L + st * SS;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[set][rt][ks] = *(const u32x4*)(base + ada[ks] + rt * 32 * 64);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb[set][ct][ks] = *(const u32x4*)(base + adb[ks] + ct * 32 * 64);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: K-tiles 0..2 requested, K-tile 0 landed and read
+  stage(0);
+  if (nkt > 1) stage(1);
+  if (nkt > 2) stage(2);
+  if (nkt > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nkt > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  readf(S0{}, 0);
+  int st_next = 1, st_free = 0;                 // ring stage of K-tile kt+1 / stage K-tile kt+3 goes to (= K-tile kt's)
+
+  auto ktile = [&](int kt, auto SET) {
+    constexpr int set = decltype(SET)::value;
+    // K-tile kt+1 has landed (this lane's share; the barrier makes it everyone's), K-tile kt's fragments have been read
+    if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0), as the builtin: hipcc's own wait insertion then knows the fragments
+                                                 // of K-tile kt are in, and does not put a lgkmcnt(0) -- which would also wait for
+                                                 // K-tile kt+1's reads -- in front of the MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nkt) readf(std::integral_constant<int, set ^ 1>{}, st_next);
+    if (kt + 3 < nkt) stage(st_free);
+    st_next = st_next == STAGES - 1 ? 0 : st_next + 1;
+    st_free = st_free == STAGES - 1 ? 0 : st_free + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) Mma<T>::step(acc[rt][ct], fa[set][rt][ks], fb[set][ct][ks]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    ktile(kt, S0{});
+    if (kt + 1 < nkt) ktile(kt + 1, S1{});
+  }
+  // every wave has passed the last K-tile's barrier with its reads retired and no DMA in flight: the ring is free
+  tile_epilogue<T, false, EPI>(p, acc, (float*)lds + wvu * 4096, wr, wc, lane, m0, n0);
 }
 
 // Shapes the 256x256 kernel takes: whole 256-column tiles, K-tiles inside one filter tap, vector epilogue, <= 32 taps,
@@ -2235,6 +2410,42 @@ static int persistent_blocks() {
   }
   const char* e = getenv("CDDMSL_PERSIST");
   return (e ? atoi(e) : 1) ? ncu : 0;
+}
+
+// The 256x128 two-workgroup kernel: whole 128-column tiles, K-tiles of 4 chunks inside one filter tap, vector epilogue.
+// CDDMSL_FWD2 (read per launch): 0 = never, 2 = wherever legal (tests, A/B), unset / 1 = the heuristic.
+static bool fwd2_legal(const ConvArgs& a) {
+  const bool vec_ok = (a.ldy % 8 == 0) && (!a.residual || a.ldr % 8 == 0) && (!a.relu_mask || a.ldm % 8 == 0);
+  if (a.pool || a.res_pool || (a.cpp & 3) || (a.Cout & 127) || !vec_ok || a.KH * a.KW > 31) return false;
+  if (2 * a.pad > a.KH - 1 || 2 * a.pad > a.KW - 1) return false;
+  return true;
+}
+static bool use_fwd2(const ConvArgs& a) {
+  const char* e = getenv("CDDMSL_FWD2");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0 || !fwd2_legal(a)) return false;
+  if (mode == 2) return true;
+  // What the 256x256 kernel does not take (Cout = 128, 384, ...; too few 256x256 tiles), when there are enough 256x128 tiles to
+  // give every CU work: per shape (two dispatches in one process) 1.14-1.31x the 128x128 kernel on the 128-channel 3x3 layers,
+  // 1.04-1.23x on their 1x1 layers; against the 256x256 kernel it loses (x0.72-0.99) on everything but K = 128.
+  if (use_gemm256(a) || g_batch_peek() != 1) return false;
+  const char* et = getenv("CDDMSL_FWD2_MIN");                   // (A/B knob)
+  return (long)(a.Cout / 128) * ((a.M + 255) / 256) >= (et ? atol(et) : 256);
+}
+template <typename T> void launch_fwd2(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  const bool taps = !(a.KH == 1 && a.KW == 1 && a.pad == 0);
+  if (sizeof(T) == 4 || a.out_f32 || a.res_f32 || a.y8) {
+    if (taps) hipLaunchKernelGGL((k_conv_fwd2<T, true, -1>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_fwd2<T, false, -1>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  if constexpr (sizeof(T) == 2) {
+    const int epi = (a.residual ? 1 : 0) | (a.relu_mask ? 2 : 0);
+#define CDDMSL_L2(TP, E) hipLaunchKernelGGL((k_conv_fwd2<T, TP, E>), grid, dim3(256), 0, st, a)
+    if (taps) { switch (epi) { case 0: CDDMSL_L2(true, 0); break; case 1: CDDMSL_L2(true, 1); break; case 2: CDDMSL_L2(true, 2); break; default: CDDMSL_L2(true, 3); } }
+    else { switch (epi) { case 0: CDDMSL_L2(false, 0); break; case 1: CDDMSL_L2(false, 1); break; case 2: CDDMSL_L2(false, 2); break; default: CDDMSL_L2(false, 3); } }
+#undef CDDMSL_L2
+  }
 }
 
 // the 256x256 kernel's epilogue variant (template parameter EPI): compile-time operand set for bf16 outputs, run-time flags otherwise
@@ -2287,6 +2498,13 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
     else if (a.cpp == 8) hipLaunchKernelGGL((k_conv3x3_small<T, 8, 2>), dim3(nb), dim3(256), 0, st, a);
     else if (a.Cout == 32) hipLaunchKernelGGL((k_conv3x3_small<T, 4, 1>), dim3(nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv3x3_small<T, 4, 2>), dim3(nb), dim3(256), 0, st, a);
+    return launch_status();
+  }
+  if (use_fwd2(a)) {
+    grid = (long)(a.Cout / 128) * ((a.M + 255) / 256);
+    g_last_kernel = 11;
+    if (g_plan_only) return CDDMSL_OK;
+    launch_fwd2<T>(a, dim3((unsigned)grid, (unsigned)g_batch), st);
     return launch_status();
   }
   if (use_gemm256(a)) {

@@ -147,7 +147,7 @@ class _Profiler:
 
 PROFILE = _Profiler()
 # cddmsl_last_kernel() ids -> profiler row names (one row per KERNEL, so the roofline object describes one kernel)
-_CONV_KERNEL = {10: "k_conv_fwd256_fp8", 1: "k_conv_fwd", 2: "k_conv_fwd_reg", 3: "k_conv_fwd256", 4: "k_conv_wgrad", 5: "k_conv_wgrad_dma", 6: "k_wgrad256", 7: "k_gemm_tn_stream", 8: "k_conv3x3_small", 9: "k_gemm_tn_small"}
+_CONV_KERNEL = {10: "k_conv_fwd256_fp8", 11: "k_conv_fwd2", 1: "k_conv_fwd", 2: "k_conv_fwd_reg", 3: "k_conv_fwd256", 4: "k_conv_wgrad", 5: "k_conv_wgrad_dma", 6: "k_wgrad256", 7: "k_gemm_tn_stream", 8: "k_conv3x3_small", 9: "k_gemm_tn_small"}
 
 
 def _timed(name):

@@ -215,6 +215,53 @@ def test_conv_fwd_256_tile_kernel(case, dtype, tol, monkeypatch):
         assert (a - b).abs().max() <= tol * a.abs().max()
 
 
+CASES_FWD2 = [
+    # N, H, W, Cin, Cout, K, pad      (Cout % 128 == 0, Cin a whole number of 32-element K-tiles in bf16 / 16 in f32)
+    (2, 19, 23, 32, 128, 3, 1),       # ragged M (874 rows), one K-tile per tap (bf16)
+    (1, 30, 33, 96, 384, 1, 0),       # three column tiles, 3 K-tiles
+    (3, 14, 14, 160, 128, 3, 1),      # 45 K-tiles
+    (1, 20, 20, 32, 256, 1, 0),       # a single K-tile (bf16)
+    (2, 16, 16, 64, 128, 1, 0),       # two K-tiles: the short prologue paths
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("case", CASES_FWD2)
+def test_conv_fwd_two_workgroup_kernel(case, dtype, tol, monkeypatch):
+    """The 256x128 two-workgroup kernel (k_conv_fwd2, forced with CDDMSL_FWD2=2) against ATen fp32 and -- bit for bit: the same
+    products accumulated in the same order -- against the kernels it replaces (CDDMSL_FWD2=0): FrozenBN scale/bias + residual +
+    ReLU forward, and the masked input-gradient form."""
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout, K, p = case
+    x = _rand((N, Cin, H, W), 51).to(dtype).float()
+    w = (_rand((Cout, Cin, K, K), 52) * (Cin * K * K) ** -0.5).to(dtype).float()
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(53)) + 0.5
+    bias = _rand((Cout,), 54, 0.1)
+    conv = F.conv2d(x, w, padding=p)
+    res = _rand(tuple(conv.shape), 55).to(dtype).float()
+    y_ref = F.relu(conv * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1) + res)
+    dev = "cuda"
+    xg = _nhwc(x).to(dev, dtype)
+    wf, _ = hip.weight_prep(w.permute(0, 2, 3, 1).contiguous().to(dev), scale.to(dev), dtype)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("CDDMSL_FWD2", mode)
+        y = hip.conv_fwd(xg, wf, scale.to(dev), bias.to(dev), _nhwc(res).to(dev, dtype), relu=True, stride=1, pad=p)
+        kern = hip._L().cddmsl_last_kernel()
+        msk = hip.conv_fwd(xg, wf, relu_mask=_nhwc(res).to(dev, dtype), stride=1, pad=p)
+        plain = hip.conv_fwd(xg, wf, stride=1, pad=p)
+        torch.cuda.synchronize()
+        assert (kern == 11) == (mode == "2"), (mode, kern)
+        out[mode] = (y.cpu(), msk.cpu(), plain.cpu())
+    err = (out["2"][0].float().permute(0, 3, 1, 2) - y_ref).abs().max() / y_ref.abs().max()
+    assert err < tol, f"fwd err {err}"
+    m_ref = conv * (res > 0)
+    errm = (out["2"][1].float().permute(0, 3, 1, 2) - m_ref).abs().max() / m_ref.abs().max()
+    assert errm < tol, f"masked err {errm}"
+    for a, b in zip(out["0"], out["2"]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("flags", [(False, False), (True, False), (False, True), (True, True)])
 def test_conv_fwd_256_persistent_form_is_bit_equal(flags, monkeypatch):
     """Short reductions (K <= 512, bf16, no taps) with more tiles than CUs run the PERSISTENT form of the 256x256 kernel (one workgroup

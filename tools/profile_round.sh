@@ -46,7 +46,7 @@ fetch, write, sq = table("fetch"), table("write"), table("sq")
 kt = glob.glob('$OUT/sq/*/*kernel_trace.csv')[0]
 dur = {r['Dispatch_Id']: (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) for r in csv.DictReader(open(kt))}
 out = {}
-for kern, name in (("k_conv_fwd256", "k_conv_fwd256"), ("k_conv_fwdI", "k_conv_fwd"), ("k_wgrad256", "k_wgrad256"), ("k_conv_wgrad_dma", "k_conv_wgrad_dma")):
+for kern, name in (("k_conv_fwd256", "k_conv_fwd256"), ("k_conv_fwd2I", "k_conv_fwd2"), ("k_conv_fwdI", "k_conv_fwd"), ("k_wgrad256", "k_wgrad256"), ("k_conv_wgrad_dma", "k_conv_wgrad_dma")):
     fk, n1 = per_launch(fetch, "FETCH_SIZE", kern)      # KiB per launch
     wk, n2 = per_launch(write, "WRITE_SIZE", kern)
     per = collections.defaultdict(dict)
