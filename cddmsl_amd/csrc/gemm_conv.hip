@@ -2231,6 +2231,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd2(ConvArgs p) {
   constexpr int SA = 256 * 64, SB = 128 * 64, SS = SA + SB, STAGES = 3;
   __shared__ __attribute__((aligned(16))) u32x4 lds[STAGES * SS / 16];
   const int t = threadIdx.x, lane = t & 63;
+#ifdef CDDMSL_TILE_STAMPS
+  const unsigned long long ts_entry = __builtin_amdgcn_s_memrealtime();
+#endif
   p.x += (long)blockIdx.y * p.bx; p.w += (long)blockIdx.y * p.bw; p.y += (long)blockIdx.y * p.by;
   const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wr = wvu >> 1, wc = wvu & 1;
@@ -2342,6 +2345,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd2(ConvArgs p) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   readf(S0{}, 0);
+#ifdef CDDMSL_TILE_STAMPS
+  const unsigned long long ts_loop = __builtin_amdgcn_s_memrealtime();
+#endif
   int st_next = 1, st_free = 0;                 // ring stage of K-tile kt+1 / stage K-tile kt+3 goes to (= K-tile kt's)
 
   auto ktile = [&](int kt, auto SET) {
@@ -2374,8 +2380,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_fwd2(ConvArgs p) {
     ktile(kt, S0{});
     if (kt + 1 < nkt) ktile(kt + 1, S1{});
   }
+#ifdef CDDMSL_TILE_STAMPS
+  asm volatile("" : "+v"(acc[3][1]));
+  const unsigned long long ts_epi = __builtin_amdgcn_s_memrealtime();
+#endif
   // every wave has passed the last K-tile's barrier with its reads retired and no DMA in flight: the ring is free
   tile_epilogue<T, false, EPI>(p, acc, (float*)lds + wvu * 4096, wr, wc, lane, m0, n0);
+#ifdef CDDMSL_TILE_STAMPS
+  if (p.tstamps && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = p.tstamps + ((long)blockIdx.x * 4 + wvu) * 4;
+    o[0] = ts_entry; o[1] = ts_loop; o[2] = ts_epi; o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // Shapes the 256x256 kernel takes: whole 256-column tiles, K-tiles inside one filter tap, vector epilogue, <= 32 taps,
