@@ -32,7 +32,9 @@ def init_distributed(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if torch.cuda.is_available():
             torch.cuda.set_device(0 if os.environ.get("CDDMSL_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0")))
-        backend = backend or os.environ.get("CDDMSL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        # (RCCL needs one device per rank: the shared-GPU rehearsal of the N > 1 path runs over gloo)
+        backend = backend or os.environ.get("CDDMSL_DIST_BACKEND") or (
+            "nccl" if torch.cuda.is_available() and not os.environ.get("CDDMSL_SHARE_GPU") else "gloo")
         dist.init_process_group(backend)
     return get_rank(), get_world_size()
 
