@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <bool LDS>
+template <int LDS>
 __global__ __launch_bounds__(512) void k_probe(const u32x4* src, float* sink, unsigned long long* stamps, int iters) {
   __shared__ u32x4 lds[4096];                                  // 64 KiB
   const int t = threadIdx.x, lane = t & 63;
@@ -28,9 +28,37 @@ __global__ __launch_bounds__(512) void k_probe(const u32x4* src, float* sink, un
   for (int k = 0; k < 4; ++k) { fa[k] = lds[(t * 4 + k) & 4095]; fb[k] = lds[(t * 4 + k + 2048) & 4095]; }
   const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
-    if (LDS) {
+    if (LDS == 1) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) { fa[k] = lds[(lane + 64 * k + 256 * (it & 7)) & 4095]; fb[k] = lds[(lane + 64 * k + 2048 + 256 * (it & 7)) & 4095]; }
+    }
+    if (LDS == 2) {                               // the conv kernels' mix: 0.75 KB of fragment reads per MFMA (24 x ds_read_b128 per 32 MFMAs)
+#pragma unroll
+      for (int rep = 0; rep < 3; ++rep)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          fa[k] = lds[(lane + 64 * k + 256 * ((it + rep) & 7)) & 4095]; fb[k] = lds[(lane + 64 * k + 2048 + 256 * ((it + rep) & 7)) & 4095];
+          asm volatile("" : "+v"(fa[k]), "+v"(fb[k]));
+        }
+    }
+    if (LDS == 3) {                               // the weight-gradient kernel's mix: the same bytes as 48 x ds_read_b64_tr_b16
+      const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+#pragma unroll
+      for (int rep = 0; rep < 3; ++rep)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned a0 = base + (((lane + 64 * k + 256 * ((it + rep) & 7)) & 4095) << 4), b0 = base + (((lane + 64 * k + 2048 + 256 * ((it + rep) & 7)) & 4095) << 4);
+          typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+          u32x2 p0, p1, q0, q1;
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(p0) : "v"(a0));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8" : "=v"(p1) : "v"(a0));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(q0) : "v"(b0));
+          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:8" : "=v"(q1) : "v"(b0));
+          if (rep == 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(p0), "+v"(p1), "+v"(q0), "+v"(q1));
+            fa[k] = u32x4{p0[0], p0[1], p1[0], p1[1]}; fb[k] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+          }
+        }
     }
 #pragma unroll
     for (int a = 0; a < 8; ++a)
@@ -45,7 +73,7 @@ __global__ __launch_bounds__(512) void k_probe(const u32x4* src, float* sink, un
   if (t == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <bool LDS> static void run(const char* what, int threads, const u32x4* src, float* sink, unsigned long long* stamps, int nblk) {
+template <int LDS> static void run(const char* what, int threads, const u32x4* src, float* sink, unsigned long long* stamps, int nblk) {
   const int iters = 4000;
   auto t0 = std::chrono::steady_clock::now();
   int launches = 0;
@@ -84,9 +112,11 @@ int main() {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   printf("device %s, %d CUs, clockRate %d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
   printf("MFMA peak at clock f: f x 256 CUs x 4 SIMDs x (2*32*32*16 FLOP / 32 cycles) = f[GHz] x 1048.6 TFLOP/s; 2.4 GHz -> 2517\n");
-  run<false>("bare MFMA, operands in registers", 256, src, sink, stamps, nblk);
-  run<false>("bare MFMA, operands in registers", 512, src, sink, stamps, nblk);
-  run<true>("MFMA + ds_read_b128 operand re-reads", 256, src, sink, stamps, nblk);
-  run<true>("MFMA + ds_read_b128 operand re-reads", 512, src, sink, stamps, nblk);
+  run<0>("bare MFMA, operands in registers", 256, src, sink, stamps, nblk);
+  run<0>("bare MFMA, operands in registers", 512, src, sink, stamps, nblk);
+  run<1>("MFMA + ds_read_b128 operand re-reads", 256, src, sink, stamps, nblk);
+  run<1>("MFMA + ds_read_b128 operand re-reads", 512, src, sink, stamps, nblk);
+  run<2>("MFMA + 0.75 KB/MFMA of ds_read_b128", 512, src, sink, stamps, nblk);
+  run<3>("MFMA + 0.75 KB/MFMA of ds_read_b64_tr_b16", 512, src, sink, stamps, nblk);
   return 0;
 }
