@@ -243,8 +243,8 @@ class RPN(nn.Module):
         pos_g, neg_g, _, _ = st["global"]
         flat = labels.view(-1)
         flat.fill_(-1)
-        flat[pos_g] = 1
-        flat[neg_g] = 0
+        flat.index_fill_(0, pos_g, 1)               # (``flat[pos_g] = 1`` stages its scalar through a synchronizing host-to-device copy)
+        flat.index_fill_(0, neg_g, 0)
         self.last_pos_global = pos_g
         return labels, matched
 
@@ -277,8 +277,10 @@ class RPN(nn.Module):
         mbox = gt_cat[midx.view(-1)[pos_g] + gt_off[img]]          # an image without boxes has no positives, so no row of it is read
         gt_d = get_deltas(anchors[a], mbox, self.weights)
         loc = torch.abs(deltas.reshape(-1, 4)[pos_g] - gt_d).sum()
+        # (weight = validity instead of ``logits[valid]``: a boolean-mask gather sizes its result on the host -- a device sync in
+        # the middle of the step; ignored anchors (-1) contribute exactly 0 to the sum and to the gradient either way)
         valid = gl >= 0
-        obj = F.binary_cross_entropy_with_logits(logits[valid], gl[valid].to(torch.float32), reduction="sum")
+        obj = F.binary_cross_entropy_with_logits(logits, gl.clamp(min=0).to(torch.float32), weight=valid.to(torch.float32), reduction="sum")
         norm = self.batch_size_per_image * n
         out = {"loss_rpn_cls": obj / norm, "loss_rpn_loc": loc / norm}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
