@@ -1660,6 +1660,20 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
   for (int nt = 0; nt < NT; ++nt) { sc[nt] = p.scale ? p.scale[nt * 32 + r] : 1.f; bi[nt] = p.bias ? p.bias[nt * 32 + r] : 0.f; }
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
   const int ntiles = (p.M + 31) >> 5;
+  // Addressing.  An ablation of this kernel (round 2: loads, MFMAs and stores switched off one at a time) showed 40-50 % of its time
+  // to be the per-tile INDEX ARITHMETIC alone -- per k-step a tap select, two range tests and a 64-bit address, per output element a
+  // 64-bit address and a row test: ~530 vector-ALU instructions per 32-pixel tile against 36-72 MFMAs.  Now: buffer addressing
+  // (32-bit lane offset from the tensor base; the k-step's tap / chunk offset is wave-uniform and rides in soffset), tap validity as
+  // a 9-bit mask per tile whose bit sets bit 31 of the lane offset (out of range -> zeros), and buffer stores with the row offset in
+  // soffset; rows past M fall outside num_records.  (One chunk per pixel, CPP = 1: a k-step's two chunks straddle taps -- lane halves
+  // differ by more than a constant -- and that instantiation keeps its direct loads.)
+  // (base one row and one pixel BEFORE the tensor: the lane offset of a pixel's tap (0,0) is then never negative -- the range check
+  // sees the lane offset alone -- and the bytes in front of the tensor are only ever addressed by taps the mask removes)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x - (long)(p.Wi + 1) * (CPP * 16)), 0, 0x7fffffff, 0x00020000);
+  const long ybytes = (long)p.M * p.ldy * ES, mbytes = (long)p.M * p.ldm * ES;
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)(ybytes > 0x7fffffffL ? 0x7fffffffL : ybytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, p.relu_mask ? (int)(mbytes > 0x7fffffffL ? 0x7fffffffL : mbytes) : 0, 0x00020000);
+  const float relu_floor = p.relu ? 0.f : -__builtin_inff();
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int m = tile * 32 + r;
     const bool vm = m < p.M;
@@ -1667,20 +1681,31 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
     const unsigned tq = fdiv(mm, p.dWo), ox = mm - tq * p.Wo;
     const unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
     const int iy0 = (int)oy * p.stride - 1, ix0 = (int)ox * p.stride - 1;
-    const char* base = p.x + (((long)img * p.Hi + iy0) * p.Wi + ix0) * (CPP * 16);
+    // byte offset of tap (0,0), chunk 0 of this lane's pixel (may be "negative": wraps, and is then masked by the tap test)
+    const unsigned lbase = (unsigned)((((int)img * p.Hi + iy0 + 1) * p.Wi + ix0 + 1) * (CPP * 16)) + (CPP > 1 ? hh * 16 : 0);
+    unsigned bad = vm ? 0u : 0x1ffu;                // bit (3 ky + kx): that tap of this pixel is outside the image
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        if ((unsigned)(iy0 + ky) >= (unsigned)p.Hi || (unsigned)(ix0 + kx) >= (unsigned)p.Wi) bad |= 1u << (3 * ky + kx);
     u32x4 a[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      // this lane's chunk: q = 2ks + hh -> (tap, chunk within the pixel); both alternatives are compile-time, hh selects
       const int q0 = 2 * ks, q1 = 2 * ks + 1;
       const int t0 = q0 / CPP, c0 = q0 % CPP, t1 = q1 / CPP, c1 = q1 % CPP;
-      const int ky = hh ? t1 / 3 : t0 / 3, kx = hh ? t1 % 3 : t0 % 3, cc = hh ? c1 : c0;
-      const bool inq = hh ? (q1 < KC) : (q0 < KC);
-      const int iy = iy0 + ky, ix = ix0 + kx;
-      const bool ok = vm && inq && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *(const u32x4*)(base + ((long)ky * p.Wi + kx) * (CPP * 16) + cc * 16);
-      a[ks] = v;
+      if (CPP > 1) {                                // both chunks in tap t0, the upper half-wave one chunk further (in lbase)
+        const unsigned v = lbase | (__builtin_amdgcn_ubfe(bad, (unsigned)t0, 1u) << 31);
+        a[ks] = __builtin_amdgcn_raw_buffer_load_b128(rx, v, ((t0 / 3) * p.Wi + (t0 % 3)) * (CPP * 16) + c0 * 16, 0);
+      } else {                                      // (direct loads: measured faster than the buffer form here, 120 vs 144 us on the first stem layer)
+        const int ky = hh ? t1 / 3 : t0 / 3, kx = hh ? t1 % 3 : t0 % 3, cc = hh ? c1 : c0;
+        const bool inq = hh ? (q1 < KC) : (q0 < KC);
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        const bool ok = vm && inq && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) v = *(const u32x4*)(p.x + ((((long)img * p.Hi + iy0) * p.Wi + ix0) + (long)ky * p.Wi + kx) * (CPP * 16) + cc * 16);
+        a[ks] = v;
+      }
     }
     f32x16 acc[NT];
 #pragma unroll
@@ -1696,17 +1721,23 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
         if (WLDS) Mma<T>::step(acc[nt], a[ks], wl[(nt * KS + ks) * 64 + wlane]);
         else Mma<T>::step(acc[nt], a[ks], bw[WLDS ? 0 : nt][WLDS ? 0 : ks]);
       }
+    // element (row (g&3) + 8(g>>2) + 4hh of the tile, channel 32 nt + r): lane offset once, the row in soffset
+    const unsigned vy = (unsigned)(((tile * 32 + 4 * hh) * p.ldy + r) * ES), vmk = (unsigned)(((tile * 32 + 4 * hh) * p.ldm + r) * ES);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const int mo = tile * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
-        if (mo < p.M) {
-          float v = affine<T>(acc[nt][g], sc[nt], bi[nt]);
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (p.relu_mask && !(Mma<T>::load(p.relu_mask + ((long)mo * p.ldm + nt * 32 + r) * ES) > 0.f)) v = 0.f;
-          Mma<T>::store(p.y + ((long)mo * p.ldy + nt * 32 + r) * ES, v);
+        const int row = (g & 3) + 8 * (g >> 2);
+        float v = affine<T>(acc[nt][g], sc[nt], bi[nt]);
+        asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "s"(relu_floor));
+        if (p.relu_mask) {
+          float mv;
+          if (ES == 2) mv = bf2f((unsigned)__builtin_amdgcn_raw_buffer_load_b16(rm, vmk, (row * p.ldm + nt * 32) * ES, 0));
+          else mv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, vmk, (row * p.ldm + nt * 32) * ES, 0));
+          if (!(mv > 0.f)) v = 0.f;
         }
+        if (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)f2bf(v), ry, vy, (row * p.ldy + nt * 32) * ES, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vy, (row * p.ldy + nt * 32) * ES, 0);
       }
   }
 }
