@@ -1492,7 +1492,7 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
       // phase 2
       CDDMSL_READ_B(1, fb1)
       CDDMSL_FLIP_B()
-      if (more2) stageD(I0{}, d, kt + 2);
+      if (more2) { stageD(I0{}, d, kt + 2); validX(kt + 2); }     // (the tap tests of the X stages of phases 3 and 4: this phase has the lighter load part)
       CDDMSL_PHASE_SYNC_IN(CDDMSL_WAIT4(fb1))
       CDDMSL_MMA_QUAD(0, 1, fa0, fb1);
       CDDMSL_PHASE_SYNC_OUT(0, 1)
@@ -1500,7 +1500,6 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
       CDDMSL_READ_A(1, fa1)
       CDDMSL_FLIP_A()
       if (more2) {
-        validX(kt + 2);
         stageX(I0{}, d, kt + 2);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
