@@ -84,6 +84,12 @@ struct ConvArgs {
   char* y8 = nullptr;
   const float* q8 = nullptr;
   unsigned* amax8 = nullptr;
+  // split-K form of the 256x256 kernel (the tail of a launch whose tile count leaves the last round of workgroups nearly empty):
+  // block b computes K-tiles [kper * (b % ksplits), ...) of logical tile tile0 + b / ksplits and stores its raw accumulators, in
+  // fragment order, at partial[b]; k_conv_split_reduce sums a tile's splits and applies the epilogue.  tile_limit: the main
+  // launch stops at this logical tile (persistent form; the one-tile grid is simply shorter).
+  float* partial = nullptr;
+  int tile0 = 0, ksplits = 1, kper = 0, tile_limit = 0;
 #ifdef CDDMSL_STAMPS
   unsigned long long* stamps;   // diagnostic build only (scratch/k256.hip): per-wave cycle sums of the phase segments
 #endif
@@ -1983,14 +1989,16 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4
 // PERSIST: one workgroup per CU walks the tiles  first + i * gridDim.x  (the XCD-contiguous order xcd_remap gives the one-tile grid)
 // one after the other -- nothing is carried from tile to tile (tools/tile_stamps.py: ~2.4 us pass between a workgroup's end and
 // its successor's first instruction on the CU, and ~1 us of the start-up is kernel-argument and index arithmetic).
-template <typename T, bool TAPS, bool RPOOL = false, int EPI = -1, bool PERSIST = false>
+template <typename T, bool TAPS, bool RPOOL = false, int EPI = -1, bool PERSIST = false, bool SPLITK = false>
 __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[2 * 2 * 2 * 128 * KCH];   // byte address = buf<<16 | ab<<15 | half<<14 | row*128 + slot*16
   const int t_in = threadIdx.x;
   p.x += (long)blockIdx.y * p.bx; p.w += (long)blockIdx.y * p.bw; p.y += (long)blockIdx.y * p.by;
   const int ntn = p.Cout >> 8;
-  const int ntiles = PERSIST ? ntn * ((p.M + 255) >> 8) : 0;
-  int lbid = PERSIST ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : xcd_remap(blockIdx.x, gridDim.x);
+  const int ntiles = PERSIST ? (p.tile_limit ? p.tile_limit : ntn * ((p.M + 255) >> 8)) : 0;
+  int lbid = PERSIST ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3))
+           : SPLITK ? p.tile0 + (int)(blockIdx.x / (unsigned)p.ksplits) : xcd_remap(blockIdx.x, gridDim.x);
+  const int kt0 = SPLITK ? (int)(blockIdx.x % (unsigned)p.ksplits) * p.kper : 0;      // first K-tile of this block's share
   if (PERSIST && lbid >= ntiles) return;
   for (;;) {
   int t = t_in;
@@ -2004,7 +2012,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   const int tile_n = lbid % ntn, tile_m = lbid / ntn;
   const int m0 = tile_m * 256, n0 = tile_n * 256;
   const int cl = (t & 7) ^ ((t >> 4) & 7);      // logical K chunk of this lane's LDS slot (slot ^ ((row>>1)&7))
-  const int nkt = p.Kc >> 3;
+  const int nkt = SPLITK ? min(p.kper, (p.Kc >> 3) - kt0) : (p.Kc >> 3);
   const int tpt = p.cpp >> 3;                   // K-tiles per filter tap
 
   // ---- staging state.  Sources are addressed as buffer base (per block, SGPRs) + per-lane byte offset (constant over
@@ -2059,6 +2067,16 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   const int step_row = ((p.Wi - (p.KW - 1)) * p.xrs - (p.cpp - KCH)) * 16;         // first tap of the next filter row
   int left[2] = {tpt, tpt}, tap[2] = {0, 0}, kxs[2] = {0, 0};
   unsigned soa[2] = {0, 0}, sob[2] = {0, 0};
+  if (SPLITK) {                                 // the streams start at K-tile kt0: inside filter tap kt0 / tpt
+    const int tap0 = TAPS ? kt0 / tpt : 0, within = TAPS ? kt0 - tap0 * tpt : kt0;
+    const int ky0 = TAPS ? tap0 / p.KW : 0, kx0 = tap0 - ky0 * p.KW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      left[h] = tpt - (TAPS ? within : 0); tap[h] = tap0; kxs[h] = kx0;
+      soa[h] = (unsigned)((ky0 * p.Wi + kx0) * p.xrs * 16 + within * KCH * 16);
+      sob[h] = (unsigned)(kt0 * KCH * 16);
+    }
+  }
 
   char* const L = (char*)lds;
   auto stageA = [&](auto H, int buf) {
@@ -2228,6 +2246,19 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
 #undef CDDMSL_PHASE_SYNC_OUT
 #undef CDDMSL_STAMP
 
+  if (SPLITK) {                                   // raw accumulators, fragment order: 32 x 16 bytes per lane, 1 KiB per wave instruction
+    f32x4* dst = (f32x4*)p.partial + (long)blockIdx.x * (8 * 32 * 64) + (wvu * 32) * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = {acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]};
+          dst[((a * 2 + b) * 4 + g4) * 64] = v;
+        }
+    return;
+  }
   tile_epilogue<T, RPOOL, EPI>(p, acc, (float*)lds + wvu * 4096, wr, wc, lane, m0, n0);
 #ifdef CDDMSL_TILE_STAMPS
   if (p.tstamps && lane == 0) {
@@ -2446,17 +2477,49 @@ static bool use_gemm256(const ConvArgs& a) {
 }
 
 
+// Sum of a tile's K-splits + the epilogue (bf16 output; scale / bias, residual, ReLU, ReLU mask): one thread per 16-byte slot of
+// the fragment-ordered partials = four consecutive rows of one output column.  Only ever a handful of tiles per launch.
+__global__ __launch_bounds__(256) void k_conv_split_reduce(ConvArgs p) {
+  const int tile_rel = blockIdx.x >> 6, q = (blockIdx.x & 63) * 256 + threadIdx.x;
+  const f32x4* src = (const f32x4*)p.partial + (long)tile_rel * p.ksplits * 16384 + q;
+  f32x4 sum = src[0];
+  for (int s = 1; s < p.ksplits; ++s) sum += src[(long)s * 16384];
+  const int wvu = q >> 11, j = (q >> 6) & 31, lane = q & 63, r32 = lane & 31, hh = lane >> 5;
+  const int a = j >> 3, b = (j >> 2) & 1, g4 = j & 3, wr = wvu >> 2, wc = wvu & 3;
+  const int ntn = p.Cout >> 8, lbid = p.tile0 + tile_rel;
+  const int tile_n = lbid % ntn, tile_m = lbid / ntn;
+  const int n = tile_n * 256 + wc * 64 + b * 32 + r32;
+  const int mrow = tile_m * 256 + wr * 128 + a * 32 + 8 * g4 + 4 * hh;
+  const float sc = p.scale ? p.scale[n] : 1.f, bi = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long m = mrow + e;
+    if (m >= p.M) break;
+    float v = __builtin_fmaf(sum[e], sc, bi);
+    if (p.residual) v += bf2f(*(const unsigned short*)(p.residual + (m * p.ldr + n) * 2));
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.relu_mask && !(bf2f(*(const unsigned short*)(p.relu_mask + (m * p.ldm + n) * 2)) > 0.f)) v = 0.f;
+    *(unsigned short*)(p.y + (m * p.ldy + n) * 2) = f2bf(v);
+  }
+}
+
+static void* g_ws = nullptr;       // device workspace for split reductions (cddmsl_set_workspace); process-wide: one device per process
+static long g_ws_bytes = 0;
+
 // Workgroups of the persistent form of the 256x256 kernel: one per CU (a multiple of 8, dealt round-robin over the XCDs), or 0 = use
 // the one-tile-per-workgroup grid (CDDMSL_PERSIST=0; read per launch, so one process can A/B).
-static int persistent_blocks() {
+static int persistent_blocks_raw() {
   static int ncu = -1;
   if (ncu < 0) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
     ncu = (n / 8) * 8;
   }
+  return ncu;
+}
+static int persistent_blocks() {
   const char* e = getenv("CDDMSL_PERSIST");
-  return (e ? atoi(e) : 1) ? ncu : 0;
+  return (e ? atoi(e) : 1) ? persistent_blocks_raw() : 0;
 }
 
 // The 256x128 two-workgroup kernel: whole 128-column tiles, K-tiles of 4 chunks inside one filter tap, vector epilogue.
@@ -2495,10 +2558,39 @@ template <typename T> void launch_fwd2(const ConvArgs& a, dim3 grid, hipStream_t
   }
 }
 
+template <typename T, bool TAPS> void launch256_main(const ConvArgs& a, dim3 grid, hipStream_t st, int epi);
 // the 256x256 kernel's epilogue variant (template parameter EPI): compile-time operand set for bf16 outputs, run-time flags otherwise
 template <typename T, bool TAPS> void launch256(const ConvArgs& a, dim3 grid, hipStream_t st) {
   if (sizeof(T) == 4 || a.out_f32 || a.res_f32 || a.y8) { hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, -1>), grid, dim3(512), 0, st, a); return; }
   const int epi = (a.residual ? 1 : 0) | (a.relu_mask ? 2 : 0);
+  // Tail of a badly quantised launch.  16 x 50 x 83 pixels are 260 row panels: a 256-column layer of res4 is 260 tiles for 256 CUs --
+  // two rounds of workgroups, the second with 4 of them (15 + 16 such launches per step, ~55 and ~30 us each wasted).  When the last
+  // round would be less than an eighth full, the main launch stops at the last full round and the leftover tiles are computed
+  // split along K (every CU takes a slice; raw accumulators to the workspace) and finished by k_conv_split_reduce.
+  if constexpr (std::is_same<T, __bf16>::value) {
+    const int ncu = persistent_blocks_raw();
+    const int tiles = (int)grid.x, rem = ncu > 0 ? tiles % ncu : 0, nktot = a.Kc >> 3;
+    const char* et = getenv("CDDMSL_TAIL_SPLIT");
+    if (!(et && atoi(et) == 0) && grid.y == 1 && tiles > ncu && rem > 0 && rem * 8 <= ncu && nktot >= 16 && g_ws) {
+      int S = ncu / rem;
+      if (S > nktot / 2) S = nktot / 2;
+      { const char* es = getenv("CDDMSL_TAIL_MAXS"); if (es && S > atoi(es)) S = atoi(es); }      // (A/B knob)
+      const int kper = (nktot + S - 1) / S;
+      S = (nktot + kper - 1) / kper;
+      if (S >= 2 && (long)rem * S * 65536 * 4 <= g_ws_bytes) {
+        ConvArgs m = a, t = a;
+        m.tile_limit = tiles - rem;
+        launch256_main<T, TAPS>(m, dim3((unsigned)(tiles - rem), 1), st, epi);
+        t.partial = (float*)g_ws; t.tile0 = tiles - rem; t.ksplits = S; t.kper = kper;
+        hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, -1, false, true>), dim3((unsigned)(rem * S)), dim3(512), 0, st, t);
+        hipLaunchKernelGGL(k_conv_split_reduce, dim3((unsigned)(rem * 64)), dim3(256), 0, st, t);
+        return;
+      }
+    }
+  }
+  launch256_main<T, TAPS>(a, grid, st, epi);
+}
+template <typename T, bool TAPS> void launch256_main(const ConvArgs& a, dim3 grid, hipStream_t st, int epi) {
   // Persistent form (bf16, no taps) for SHORT reductions only: per shape, two builds in one process, K <= 512 layers gain 4-6 %
   // (the ~2.4 us between workgroups is 10-20 % of such a tile), K >= 2048 layers lose 2-4 % against the hardware's dynamic
   // dispatch; in the step k_conv_fwd256 50.9 -> 50.4 ms.
@@ -2732,8 +2824,6 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const f32x4* ws, float* dw
     if (n + e < Cout) dw[(long)(n + e) * ldo + k] += sum[e] * (scale ? scale[n + e] : 1.f);
 }
 
-static void* g_ws = nullptr;       // device workspace for split reductions (cddmsl_set_workspace); process-wide: one device per process
-static long g_ws_bytes = 0;
 extern "C" int cddmsl_set_workspace(void* ptr, long bytes) {
   if (bytes < 0 || (ptr == nullptr && bytes != 0) || ((size_t)ptr & 15)) return CDDMSL_ERR_ARG;
   g_ws = ptr; g_ws_bytes = bytes;

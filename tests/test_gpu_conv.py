@@ -215,6 +215,43 @@ def test_conv_fwd_256_tile_kernel(case, dtype, tol, monkeypatch):
         assert (a - b).abs().max() <= tol * a.abs().max()
 
 
+@pytest.mark.parametrize("case", [(1, 66560, 1, 512, 256, 1, 0), (13, 64, 80, 320, 256, 3, 1), (1, 66304, 1, 1024, 1024, 1, 0)])
+@pytest.mark.parametrize("flags", [(False, False), (True, False), (True, True)])
+def test_conv_fwd_256_tail_tiles_split_along_k(case, flags, monkeypatch):
+    """260 row panels on 256 CUs: the main launch of the 256x256 kernel stops at the last full round of workgroups and the
+    leftover tiles are computed split along K (raw accumulators through the workspace, k_conv_split_reduce applies the
+    epilogue) -- against ATen fp32, and against the unsplit launch (CDDMSL_TAIL_SPLIT=0) to one bf16 rounding of the output
+    (same products; the K-slices are summed in a different order).  1x1 and 3x3 (5 K-tiles per tap, slices of 3: they start and end inside taps)."""
+    from cddmsl_amd import hip
+    res_on, msk_on = flags
+    N, H, W, Cin, Cout, K, p = case
+    dev, dtype = "cuda", torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(61)
+    x = torch.randn(N, H, W, Cin, device=dev, generator=g).to(dtype)
+    w = (torch.randn(Cout, K, K, Cin, device=dev, generator=g) * (Cin * K * K) ** -0.5).to(dtype)
+    scale = torch.rand(Cout, device=dev, generator=g) + 0.5
+    bias = torch.randn(Cout, device=dev, generator=g) * 0.1
+    res = torch.randn(N, H, W, Cout, device=dev, generator=g).to(dtype) if res_on else None
+    msk = torch.randn(N, H, W, Cout, device=dev, generator=g).to(dtype) if msk_on else None
+    hip.ensure_workspace(dev)
+    monkeypatch.setenv("CDDMSL_GEMM256", "2")
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CDDMSL_TAIL_SPLIT", mode)
+        out[mode] = hip.conv_fwd(x, w, scale, bias, res, relu=not msk_on, relu_mask=msk, stride=1, pad=p)
+        assert hip._L().cddmsl_last_kernel() == 3
+    torch.cuda.synchronize()
+    a, b = out["0"].float(), out["1"].float()
+    assert not torch.equal(a[-1], b[-1]) or K == 1            # (the tail tiles did take the other path: last rows differ in rounding)
+    assert (a - b).abs().max() <= 2.0 ** -7 * a.abs().max()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=p).permute(0, 2, 3, 1) * scale + bias
+    if res_on:
+        ref = ref + res.float()
+    ref = ref * (msk.float() > 0) if msk_on else ref.clamp_min(0)
+    err = (b - ref).abs().max() / ref.abs().max()
+    assert err < 2e-2, err
+
+
 CASES_FWD2 = [
     # N, H, W, Cin, Cout, K, pad      (Cout % 128 == 0, Cin a whole number of 32-element K-tiles in bf16 / 16 in f32)
     (2, 19, 23, 32, 128, 3, 1),       # ragged M (874 rows), one K-tile per tap (bf16)
