@@ -176,6 +176,7 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
     residual_pooled=True: ``residual`` is [N, Ho//2, Wo//2, Cout] and every output pixel adds a quarter of its pooled pixel
     (the backward of AvgPool2d(2) fused into the epilogue; pooled tensor < 2 GiB -- see ``pooled_residual_ok``)."""
     require_cuda(x, w, scale, bias, residual, relu_mask)
+    ensure_workspace(x.device)                       # (the split-K tail of badly quantised launches goes through it)
     assert x.dim() == 4 and w.dim() == 4 and x.is_contiguous() and w.is_contiguous()
     assert x.dtype == w.dtype
     N, H, W, Cin = x.shape
