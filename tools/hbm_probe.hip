@@ -8,6 +8,7 @@
 //   add       y = a + b                                 (2 R : 1 W)     residual epilogues
 //   expand    y[m][0:4c] = f(a[m][0:c]) + r[m][0:4c]    (1.25 R : 1 W by rows: c in, 4c residual in, 4c out)
 //                                                       the N = 4K 1x1 layers (K = 512 -> N = 2048 with residual)
+//   L2 -> LDS what buffer_load ... lds delivers from an L2-resident buffer with nothing else running (the conv kernels' operand path)
 // Rates are ALGORITHMIC bytes / time.  build + run:
 //   hipcc --offload-arch=gfx950 -O3 tools/hbm_probe.hip -o /tmp/hbm_probe && /tmp/hbm_probe
 #include <hip/hip_runtime.h>
@@ -36,6 +37,26 @@ __global__ __launch_bounds__(256) void k_expand(const u32x4* a, const u32x4* r, 
     const u32x4* ar = a + row * c;
     for (int j = threadIdx.x; j < 4 * c; j += 256) { u32x4 u = ar[j & (c - 1)], v = r[row * 4 * c + j]; y[row * 4 * c + j] = u + v; }
   }
+}
+
+// L2 -> LDS: every workgroup (512 threads, one per CU) streams 64 KiB tiles of ONE 2 MiB buffer (L2-resident in every XCD after the
+// first pass) into LDS with buffer_load ... lds, 16 bytes per lane, the conv kernels' operand path without their compute
+__global__ __launch_bounds__(512) void k_l2_to_lds(const char* a, int iters, unsigned* sink) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][4096];          // 2 x 64 KiB
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a, 0, 0x7fffffff, 0x00020000);
+  const int t = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  unsigned tile = blockIdx.x & 31;
+  for (int it = 0; it < iters; ++it) {
+    char* dst = (char*)lds[it & 1] + wv * 1024;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, (int)(t * 16 + i * 8192), (int)(tile * 65536), 0, 0);
+    tile = (tile + 1) & 31;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 // the previous tile has landed; this one stays in flight
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (lds[0][t][0] == 0x12345u) sink[0] = 1;
 }
 
 template <typename F> static float timed(F launch) {
@@ -76,6 +97,11 @@ int main() {
     const long rows = n / (4 * c);
     t = timed([&] { hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, 0, a, b, y, rows, c); });
     printf("  expand %.2f\n", (double)rows * c * 9 * 16 / t / 1e9);
+  }
+  {
+    const int iters = 2000;
+    float tl = timed([&] { hipLaunchKernelGGL(k_l2_to_lds, dim3(prop.multiProcessorCount), dim3(512), 0, 0, (const char*)a, iters, sink); });
+    printf("L2 -> LDS (buffer_load ... lds, 64 KiB tiles of a 2 MiB buffer, one 512-thread workgroup per CU)  %.2f TB/s\n", (double)prop.multiProcessorCount * iters * 65536.0 / tl / 1e9);
   }
   float t = timed([&] { hipMemcpyAsync(y, a, bytes, hipMemcpyDeviceToDevice, 0); });
   printf("hipMemcpyAsync D2D copy %.2f\n", 2.0 * bytes / t / 1e9);
