@@ -1795,8 +1795,12 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 // 11 us with a residual, against ~1 us of vector-ALU work.
 // `ep`: 16 KiB of LDS private to the wave.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool RPOOL, int EPI>
-__device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4][2], float* ep, int wr, int wc, int lane, int m0, int n0) {
+// PRE: the rows of the first two passes of ONE operand (the residual if there is one, else the ReLU mask) were requested by the caller
+// -- the 256x256 kernel issues them in phase 3 of the tile's last K-tile, into the registers the A0 fragments no longer need -- and
+// arrive in `pre`.
+template <typename T, bool RPOOL, int EPI, bool PRE = false>
+__device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4][2], float* ep, int wr, int wc, int lane, int m0, int n0,
+                                              const u32x4 (*pre)[4] = nullptr) {
   constexpr int ES = Mma<T>::ES;
   const int r32 = lane & 31, hh = lane >> 5;
   const int cg = lane & 7, rr = lane >> 3;
@@ -1860,7 +1864,17 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4
         if (has_msk) rmsk_[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, (a * 32 + 8 * i) * p.ldm * ES + q * 16, 0);
       }
   };
-  if (DEPTH == 2 && !rf32) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
+  if (PRE && DEPTH == 2) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (EPI & 1) {
+          rresb[d % DEPTH][i][0] = pre[d][i];
+          if (EPI & 2) rmskb[d % DEPTH][i][0] = __builtin_amdgcn_raw_buffer_load_b128(rmsk, vm, (d * 32 + 8 * i) * p.ldm * ES, 0);
+        } else rmskb[d % DEPTH][i][0] = pre[d][i];
+      }
+  } else if (DEPTH == 2 && !rf32) { fetch(0, rresb[0], rmskb[0]); fetch(1, rresb[DEPTH - 1], rmskb[DEPTH - 1]); }
   auto put = [&](auto A) {                          // accumulator rows 32a..32a+31 -> transposition buffer a & 1
     constexpr int a = decltype(A)::value;
 #pragma unroll
@@ -2193,6 +2207,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   // (Tried here and measured slower, +1 ms of kernel time per step: starting the epilogue's residual / mask rows on their way from HBM
   // with one dword load per 128-byte line -- a lane per row -- during this last K-tile.  The epilogue's first pass does wait ~2 us
   // for its operand rows, but 64 single-line requests per instruction cost the load path more than the wait.)
+  // the epilogue's first operand rows ride in the A0 fragments' registers from phase 3 of the last K-tile on (see tile_epilogue PRE)
+  constexpr bool PREF = EPI > 0 && !RPOOL && Mma<T>::ES == 2 && !SPLITK;
+  u32x4 pre[2][4];
   auto ktile = [&](int kt, auto LAST) {
     constexpr bool last = decltype(LAST)::value;
     const int d = kt & 1;
@@ -2218,6 +2235,18 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else if (more1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (PREF) {
+      const bool is_res = (EPI & 1) != 0;
+      const char* base = is_res ? p.residual : p.relu_mask;
+      const int ld = is_res ? p.ldr : p.ldm;
+      long bytes = ((long)p.M - m0) * ld * 2;
+      if (bytes > 0x7fffffffL) bytes = 0x7fffffffL;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)m0 * ld * 2), 0, (int)bytes, 0x00020000);
+      const unsigned vo = (unsigned)(((wr * 128 + (lane >> 3)) * ld + n0 + wc * 64 + (lane & 7) * 8) * 2);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[a][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (a * 32 + 8 * i) * ld * 2, 0);
     }
     CDDMSL_PHASE_SYNC_IN();
     CDDMSL_MMA_QUAD(1, 1, fa1, fb1);
@@ -2259,7 +2288,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
         }
     return;
   }
-  tile_epilogue<T, RPOOL, EPI>(p, acc, (float*)lds + wvu * 4096, wr, wc, lane, m0, n0);
+  tile_epilogue<T, RPOOL, EPI, PREF>(p, acc, (float*)lds + wvu * 4096, wr, wc, lane, m0, n0, pre);
 #ifdef CDDMSL_TILE_STAMPS
   if (p.tstamps && lane == 0) {
     if (!PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (exit stamp = the wave's stores have left)
