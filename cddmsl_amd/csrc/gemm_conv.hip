@@ -1798,9 +1798,10 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 // PRE: the rows of the first two passes of ONE operand (the residual if there is one, else the ReLU mask) were requested by the caller
 // -- the 256x256 kernel issues them in phase 3 of the tile's last K-tile, into the registers the A0 fragments no longer need -- and
 // arrive in `pre`.
+// `sb` (optional): this lane's 8 scale and 8 bias values, requested by the caller ahead of time (phase 4 of the last K-tile).
 template <typename T, bool RPOOL, int EPI, bool PRE = false>
 __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4][2], float* ep, int wr, int wc, int lane, int m0, int n0,
-                                              const u32x4 (*pre)[4] = nullptr) {
+                                              const u32x4 (*pre)[4] = nullptr, const f32x4* sb = nullptr) {
   constexpr int ES = Mma<T>::ES;
   const int r32 = lane & 31, hh = lane >> 5;
   const int cg = lane & 7, rr = lane >> 3;
@@ -1808,8 +1809,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4
   float sc[8], bi[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sc[j] = p.scale ? p.scale[n + j] : 1.f;
-    bi[j] = p.bias ? p.bias[n + j] : 0.f;
+    if (sb) { sc[j] = sb[j >> 2][j & 3]; bi[j] = sb[2 + (j >> 2)][j & 3]; }
+    else { sc[j] = p.scale ? p.scale[n + j] : 1.f; bi[j] = p.bias ? p.bias[n + j] : 0.f; }
   }
   const bool has_res = EPI < 0 ? p.residual != nullptr : (EPI & 1) != 0;
   const bool has_msk = EPI < 0 ? p.relu_mask != nullptr : (EPI & 2) != 0;
@@ -2210,6 +2211,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
   // the epilogue's first operand rows ride in the A0 fragments' registers from phase 3 of the last K-tile on (see tile_epilogue PRE)
   constexpr bool PREF = EPI > 0 && !RPOOL && Mma<T>::ES == 2 && !SPLITK;
   u32x4 pre[2][4];
+  f32x4 sb[4];
   auto ktile = [&](int kt, auto LAST) {
     constexpr bool last = decltype(LAST)::value;
     const int d = kt & 1;
@@ -2254,6 +2256,12 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
     // phase 4
     if (more1) readA(I0{}, fa0);
     if (more2) stageB(I1{}, d);
+    if (last && !SPLITK) {                          // the epilogue's scale / bias values (fb1 is dead from here on)
+      const int n = n0 + wc * 64 + (lane & 7) * 8;
+      const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+      sb[0] = p.scale ? *(const f32x4*)(p.scale + n) : one; sb[1] = p.scale ? *(const f32x4*)(p.scale + n + 4) : one;
+      sb[2] = p.bias ? *(const f32x4*)(p.bias + n) : zero; sb[3] = p.bias ? *(const f32x4*)(p.bias + n + 4) : zero;
+    }
     CDDMSL_PHASE_SYNC_IN();
     CDDMSL_MMA_QUAD(1, 0, fa1, fb0);
     CDDMSL_PHASE_SYNC_OUT(1, 0);
@@ -2288,7 +2296,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd256(ConvArgs p) {
         }
     return;
   }
-  tile_epilogue<T, RPOOL, EPI, PREF>(p, acc, (float*)lds + wvu * 4096, wr, wc, lane, m0, n0, pre);
+  tile_epilogue<T, RPOOL, EPI, PREF>(p, acc, (float*)lds + wvu * 4096, wr, wc, lane, m0, n0, pre, sb);
 #ifdef CDDMSL_TILE_STAMPS
   if (p.tstamps && lane == 0) {
     if (!PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (exit stamp = the wave's stores have left)
