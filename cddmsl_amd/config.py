@@ -59,6 +59,28 @@ class CfgNode(dict):
             node[parts[-1]] = _to_node(v)
 
 
+def auto_scale_workers(cfg, num_workers):
+    """``DefaultTrainer.auto_scale_workers`` (engine/defaults.py:633-701; called from ``DefaultTrainer.__init__`` :374): a config
+    written for ``SOLVER.REFERENCE_WORLD_SIZE`` workers, run on ``num_workers``, keeps its PER-GPU batch: total batch and base LR
+    scale with the worker count, iteration counts (MAX_ITER, WARMUP_ITERS, STEPS, TEST.EVAL_PERIOD, CHECKPOINT_PERIOD) inversely.
+    Returns the config itself when ``REFERENCE_WORLD_SIZE`` is 0 or already equals ``num_workers``, a scaled clone otherwise."""
+    old = cfg.SOLVER.get("REFERENCE_WORLD_SIZE", 0)
+    if old == 0 or old == num_workers:
+        return cfg
+    cfg = cfg.clone()
+    assert cfg.SOLVER.IMS_PER_BATCH % old == 0, "Invalid REFERENCE_WORLD_SIZE in config!"
+    scale = num_workers / old
+    cfg.SOLVER.IMS_PER_BATCH = int(round(cfg.SOLVER.IMS_PER_BATCH * scale))
+    cfg.SOLVER.BASE_LR = cfg.SOLVER.BASE_LR * scale
+    cfg.SOLVER.MAX_ITER = int(round(cfg.SOLVER.MAX_ITER / scale))
+    cfg.SOLVER.WARMUP_ITERS = int(round(cfg.SOLVER.WARMUP_ITERS / scale))
+    cfg.SOLVER.STEPS = tuple(int(round(s / scale)) for s in cfg.SOLVER.STEPS)
+    cfg.TEST.EVAL_PERIOD = int(round(cfg.TEST.EVAL_PERIOD / scale))
+    cfg.SOLVER.CHECKPOINT_PERIOD = int(round(cfg.SOLVER.CHECKPOINT_PERIOD / scale))
+    cfg.SOLVER.REFERENCE_WORLD_SIZE = num_workers      # maintain the invariant
+    return cfg
+
+
 def _eval_strings(d):
     """YAML leaves like "(480, 512)" are python tuples in the reference's configs."""
     if isinstance(d, dict):

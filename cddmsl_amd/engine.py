@@ -52,8 +52,14 @@ class GradBuckets:
     first stages, written last) are reduced then.  A write into a bucket that is already on the wire would corrupt the step, so
     it raises (``CDDMSL_OVERLAP_ALLREDUCE=0`` switches the overlap off)."""
 
-    def __init__(self, params, bucket_bytes=64 << 20):
+    def __init__(self, params, bucket_bytes=64 << 20, compression=None):
         self.params = [p for p in params if p.requires_grad]
+        # optional gradient compression on the wire (engine/defaults.py:75-78 registers torch's fp16_compress_hook: cast, divide by
+        # the world size, all-reduce, cast back).  "bf16" keeps the f32 exponent range (no loss scaling needed) and halves the
+        # 193.6 MB the ring moves; "fp16" is the reference's own choice.  The f32 flat buffer stays the accumulator on each rank.
+        compression = compression if compression is not None else (os.environ.get("CDDMSL_GRAD_COMPRESSION") or None)
+        assert compression in (None, "bf16", "fp16"), compression
+        self.compression = {None: None, "bf16": torch.bfloat16, "fp16": torch.float16}[compression]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -88,6 +94,7 @@ class GradBuckets:
         self._open = None             # per-bucket number of parameters not finished yet
         self._launched, self._ready, self._handles = set(), [], []
         self._comm_stream = None
+        self._wire = [None] * len(self.buckets)   # compressed copies of the buckets (allocated on first use)
         self.launch_log = []          # (bucket, writes announced so far) per step: when each bucket went on the wire
         self._announced, self._sig = 0, None
 
@@ -120,12 +127,13 @@ class GradBuckets:
         # the launches announced by EARLIER calls are in the queue by now: buckets they completed can go
         self._flush_ready()
         k = id(p)
-        if k not in self._left:
-            return
-        for bi in self._param_buckets[k]:
+        # ANY write into a bucket that has left is an error -- also one by a parameter the counting step never saw write
+        for bi in self._param_buckets.get(k, ()):
             if bi in self._launched:
                 raise RuntimeError("GradBuckets: a gradient was written into a bucket whose all-reduce is already in flight (the "
                                    "step's kernel sequence changed); rerun with CDDMSL_OVERLAP_ALLREDUCE=0")
+        if k not in self._left:
+            return
         self._left[k] -= 1
         if self._left[k] == 0:
             for bi in self._param_buckets[k]:
@@ -137,9 +145,20 @@ class GradBuckets:
         while self._ready:
             self._launch(self._ready.pop(0))
 
+    def _reduce(self, bi):
+        """scale by 1 / world, (compress,) start the all-reduce of one bucket; returns (handle, bucket index)"""
+        b = self.buckets[bi]
+        b.mul_(1.0 / get_world_size())
+        if self.compression is None:
+            return dist.all_reduce(b, async_op=True), bi
+        if self._wire[bi] is None:
+            self._wire[bi] = torch.empty_like(b, dtype=self.compression)
+        w = self._wire[bi]
+        w.copy_(b)
+        return dist.all_reduce(w, async_op=True), bi
+
     def _launch(self, bi):
         b = self.buckets[bi]
-        ws = get_world_size()
         self._launched.add(bi)
         self.launch_log.append((bi, self._announced))
         if b.is_cuda:
@@ -149,11 +168,9 @@ class GradBuckets:
             ev.record()                                   # behind every launch enqueued so far on the compute stream
             with torch.cuda.stream(self._comm_stream):
                 self._comm_stream.wait_event(ev)
-                b.mul_(1.0 / ws)
-                self._handles.append(dist.all_reduce(b, async_op=True))
+                self._handles.append(self._reduce(bi))
         else:
-            b.mul_(1.0 / ws)
-            self._handles.append(dist.all_reduce(b, async_op=True))
+            self._handles.append(self._reduce(bi))
 
     def all_reduce_mean(self):
         """After ``backward()`` returned: start what is not on the wire yet, wait for everything."""
@@ -173,11 +190,20 @@ class GradBuckets:
         for bi in range(len(self.buckets)):
             if bi not in self._launched:
                 self._launch(bi)
-        for h in self._handles:
-            h.wait()                                      # (NCCL: the compute stream waits for the collective's stream)
+        for h, bi in self._handles:
+            if self.compression is None or not self.buckets[bi].is_cuda:
+                h.wait()                                  # (NCCL: the compute stream waits for the collective's stream)
+                if self.compression is not None:
+                    self.buckets[bi].copy_(self._wire[bi])
+            else:                                         # decompress on the side stream, behind the collective
+                with torch.cuda.stream(self._comm_stream):
+                    h.wait()
+                    self.buckets[bi].copy_(self._wire[bi])
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
-        self._handles, self._left = [], None
+        self._handles, self._left, self._open = [], None, None
+        # (a plain backward() + all_reduce_mean() without begin_backward() must reduce every bucket again: nothing stays "launched")
+        self._launched, self._ready = set(), []
 
 
 class SimpleTrainer:
@@ -240,7 +266,12 @@ class SimpleTrainer:
         # (the kernel sequence of backward depends on which branches are live and how they are composed, nothing else)
         self.buckets.begin_backward((self.iter > self.burn_in, self.share_source_pass, self.fuse_consistency,
                                      bool(self.cfg.MODEL.KD_REGULRAZIATION), len(data), tuple(sorted(loss_dict))))
-        losses.backward()
+        try:
+            losses.backward()
+        except BaseException:
+            from . import layers
+            layers._TOUCH_HOOK[0] = None              # a failed backward must not leave the announcement hook installed
+            raise
         self.buckets.all_reduce_mean()
         self.optimizer.iteration = self.iter
         self.optimizer.step()

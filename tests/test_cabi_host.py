@@ -79,6 +79,27 @@ def test_lr_schedule_kat():
     assert all(abs(v - k["lr_5_10"]) < 1e-9 for v in lrs[5:10]) and all(abs(v - k["lr_20_30"]) < 1e-9 for v in lrs[20:])
 
 
+def test_auto_scale_workers_kat():
+    """The worked example in the reference's own docstring (engine/defaults.py:649-668: a config written for 8 workers run on
+    16), REFERENCE_WORLD_SIZE 0 / equal = untouched (:676-678), and the inverse direction; the input config is not modified."""
+    from cddmsl_amd.config import auto_scale_workers, get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", 16, "SOLVER.BASE_LR", 0.1, "SOLVER.REFERENCE_WORLD_SIZE", 8, "SOLVER.MAX_ITER", 5000,
+                         "SOLVER.STEPS", (4000,), "SOLVER.CHECKPOINT_PERIOD", 1000, "SOLVER.WARMUP_ITERS", 100, "TEST.EVAL_PERIOD", 500])
+    new = auto_scale_workers(cfg, 16)
+    s = new.SOLVER
+    assert (s.IMS_PER_BATCH, s.REFERENCE_WORLD_SIZE, s.MAX_ITER, s.STEPS, s.CHECKPOINT_PERIOD) == (32, 16, 2500, (2000,), 500)
+    assert abs(s.BASE_LR - 0.2) < 1e-12 and s.WARMUP_ITERS == 50 and new.TEST.EVAL_PERIOD == 250
+    assert cfg.SOLVER.IMS_PER_BATCH == 16 and cfg.SOLVER.MAX_ITER == 5000          # a clone was scaled
+    assert auto_scale_workers(cfg, 8) is cfg
+    half = auto_scale_workers(cfg, 4).SOLVER
+    assert (half.IMS_PER_BATCH, half.MAX_ITER, half.STEPS) == (8, 10000, (8000,)) and abs(half.BASE_LR - 0.05) < 1e-12
+    plain = get_cfg()
+    assert plain.SOLVER.REFERENCE_WORLD_SIZE == 0 and auto_scale_workers(plain, 8) is plain
+    # per-GPU batch is what stays fixed (data/build.py:287)
+    assert new.SOLVER.IMS_PER_BATCH // 16 == cfg.SOLVER.IMS_PER_BATCH // 8
+
+
 def test_state_dict_keys_match_reference_names():
     """SURVEY.md section 5 (checkpoint row): reference key names load into the product model (CPU construction only)."""
     from cddmsl_amd import synthetic

@@ -178,7 +178,7 @@ def _overlap_worker(rank, world, port, ret):
         from cddmsl_amd import layers
         from cddmsl_amd.engine import GradBuckets
         g = torch.Generator().manual_seed(7)
-        shapes = [(8, 4, 3, 3), (16,), (12, 8), (6, 4, 1, 1), (40,), (5, 5)]
+        shapes = [(8, 4, 3, 3), (16,), (12, 8), (6, 4, 1, 1), (40,), (5, 5), (3,)]   # (the last one never writes in a "sig" step)
         params = [torch.nn.Parameter(torch.zeros(*s).contiguous(memory_format=torch.channels_last) if len(s) == 4 else torch.zeros(*s)) for s in shapes]
         gb = GradBuckets(params, bucket_bytes=4 * 100)           # 100 floats per bucket: several parameters per bucket, some straddling
         assert len(gb.buckets) >= 4
@@ -223,9 +223,50 @@ def _overlap_worker(rank, world, port, ret):
         except RuntimeError:
             raised = True
         layers._TOUCH_HOOK[0] = None
-        for h in gb._handles:
+        for h, _ in gb._handles:
             h.wait()
         assert raised
+        # ... and so does a write by a parameter the counting step never saw write, once its bucket has left (the announcement
+        # is checked against the buckets in flight BEFORE the per-parameter countdown is consulted)
+        gb.all_reduce_mean()
+        gb.zero()
+        gb.begin_backward(("sig",))
+        backward()
+        try:
+            layers._grad_buf(params[6]).add_(1.0)                                    # shares the last bucket with params[5]
+            layers._grad_buf(params[6]).add_(1.0)
+            raised = False
+        except RuntimeError:
+            raised = True
+        layers._TOUCH_HOOK[0] = None
+        for h, _ in gb._handles:
+            h.wait()
+        assert raised
+        gb.all_reduce_mean()
+        # a plain reduction with no begin_backward() after an overlapped step reduces EVERY bucket again (nothing stays "launched")
+        for p in params:
+            p.grad.fill_(float(rank + 1))
+        gb.all_reduce_mean()
+        for p in params:
+            assert torch.allclose(p.grad, torch.full_like(p.grad, 1.5))
+        # gradient compression on the wire (engine/defaults.py:75-78: the reference's optional fp16 hook; bf16 here): the mean of
+        # the two ranks' gradients to bf16 precision, overlapped exactly like the f32 buckets
+        mag = [torch.zeros(*s) for s in shapes]                                      # (rounding errors scale with sum |contribution|)
+        for r in range(world):
+            for i, c in zip(order, contrib[r]):
+                mag[i] += c.abs() / world
+        for comp, tol in (("bf16", 2.0 ** -8), ("fp16", 2.0 ** -11)):
+            gc = GradBuckets(params, bucket_bytes=4 * 100, compression=comp)
+            for step in range(2):
+                gc.zero()
+                gc.begin_backward(("sig",))
+                backward()
+                gc.all_reduce_mean()
+                for p, w, m in zip(params, want, mag):
+                    assert p.grad.dtype == torch.float32
+                    assert bool(((p.grad - w).abs() <= 3 * tol * m + 1e-6).all()), (comp, step)
+                assert any(not torch.equal(p.grad, w) for p, w in zip(params, want))   # (it did go through the narrow type)
+            assert any(a < total for _, a in gc.launch_log)
         ret[rank] = logs[1]
     finally:
         dist.destroy_process_group()

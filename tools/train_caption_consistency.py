@@ -53,7 +53,8 @@ def main(args):
     import torch
     from cddmsl_amd import engine, synthetic
     rank, world = engine.init_distributed()
-    cfg = setup(args)
+    from cddmsl_amd.config import auto_scale_workers
+    cfg = auto_scale_workers(setup(args), world)                              # engine/defaults.py:374
     cfg.MODEL.DEVICE = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
     torch.cuda.set_device(cfg.MODEL.DEVICE)
     per_rank = max(cfg.SOLVER.IMS_PER_BATCH // world, 1)       # data/build.py:287
