@@ -296,3 +296,33 @@ def test_sampler_streams_and_grouping_match_reference():
     for b, want in ref["groups"].items():
         got = [[d["id"] for d in batch] for batch in data.aspect_ratio_batches(iter(items), int(b))]
         assert got == want, b
+
+
+def test_clip_checkpoint_alignment_matches_reference():
+    """``convert_clip_state`` against what the reference's OWN ``align_and_update_state_dicts_for_CLIP`` returned
+    (checkpoint/clip_model_loading.py:190-343; fixture tests/golden/ref_ckpt_align.json, generator make_golden_ckpt.py): the same
+    result names, the same tensor behind each name (every checkpoint element carries a unique value), the same errors.  Cases:
+    an OpenAI-CLIP file into the model with / without an offline backbone, the second (``bb_rpn_weights``) checkpoint,
+    Caffe2-layout heads + RPN blob names + a shape mismatch, an ambiguous suffix, no match at all, longest-suffix priority."""
+    import json
+    from cddmsl_amd.checkpoint import convert_clip_state
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_ckpt_align.json")))
+    assert len(fx["cases"]) >= 7
+    for c in fx["cases"]:
+        model = {k: torch.zeros(*shp) if shp else torch.zeros(()) for k, shp in c["model"].items()}
+        ckpt = {}
+        for k, (shp, start) in c["ckpt"].items():
+            n = int(np.prod(shp)) if shp else 1
+            ckpt[k] = (torch.arange(n, dtype=torch.float32) + float(start)).view(*shp) if shp else torch.tensor(float(start))
+        if c["raises"]:
+            with pytest.raises(ValueError):
+                convert_clip_state(model, ckpt, c["bb_rpn_weights"])
+            assert c["raises"] == "ValueError"
+            continue
+        got, pairs = convert_clip_state(model, ckpt, c["bb_rpn_weights"])
+        want = dict(c["expect"])
+        want.pop("ignore_others", None)        # (the reference's marker tensor for its FrozenBN loader, clip_model_loading.py:230: not a weight)
+        assert set(got) == set(want), (c["name"], sorted(set(got) ^ set(want))[:8])
+        for k, (shp, vals) in want.items():
+            assert list(got[k].shape) == shp and got[k].flatten().tolist() == vals, (c["name"], k)
+        assert all(k in got for k in pairs)
