@@ -174,10 +174,13 @@ def main():
     # only in its last step (every step launches the same shapes);
     # which kernel that is, and the per-kernel table, come from one fully instrumented untimed step (the last warm-up step).
     full = None
+    step0 = None                                       # loss dict of the very first step (device tensors; read after the timed region)
     for i in range(args.warmup):
         if i == args.warmup - 1:
             hip.PROFILE.enable()
-        tr.run_step()
+        ld_ = tr.run_step()
+        if step0 is None:
+            step0 = ld_
     if args.warmup > 0:
         full = hip.PROFILE.collect()
     gemm_names = ("k_conv_fwd256", "k_conv_fwd2", "k_conv_fwd", "k_wgrad256", "k_conv_wgrad_dma") if args.dtype != "fp8" else ("k_conv_fwd256_fp8",)
@@ -192,6 +195,8 @@ def main():
         if i == args.steps - 1:                        # the dominant kernel's launches of the LAST timed step carry the events
             hip.PROFILE.enable(only={dom_name})
         last = tr.run_step()
+        if step0 is None:
+            step0 = last
     barrier()
     dt = time.perf_counter() - t0
     dom_shapes = hip.PROFILE.by_shape()
@@ -230,6 +235,17 @@ def main():
         dist.all_gather_object(dl, torch.cuda.current_device())
         devs = dl
     losses = {k: float(v.detach()) for k, v in last.items()}
+    # Outside the timed region: the FIRST step's losses (seeded weights, seeded batch, seeded samplers) against the fixture that
+    # tests/test_gpu_bench_gate.py ties to the exact-f32 step at these very launch shapes -- the bench is timing the gated computation.
+    gate = None
+    fpath = os.path.join(ROOT, "tests", "golden", "bench_step0_losses.json")
+    fkey = f"{args.dtype}_b{args.batch}_{args.height}x{args.width}"
+    if world == 1 and os.path.exists(fpath):
+        fx = json.load(open(fpath)).get(fkey)
+        if fx is not None:
+            s0 = {k: float(v.detach()) for k, v in step0.items()}
+            dev = max(abs(s0[k] - v) / (abs(v) + 5e-2) for k, v in fx.items())
+            gate = {"fixture": "tests/golden/bench_step0_losses.json:" + fkey, "step0_losses": s0, "max_rel_dev": dev, "tolerance": 2e-2, "ok": dev <= 2e-2}
 
     if rank == 0:
         gb = args.batch * world
@@ -283,6 +299,7 @@ def main():
             "kernels_ms_note": "one fully instrumented untimed step (event pairs on every launch: that step runs ~5 % slower)",
             "kernels_tflops": {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in full.items() if v["ms"] > 0 and v["flops"] > 0},
             "losses": losses,
+            "losses_gate": gate,
         }
         if fwd_ms is not None:
             ftf = 1.878 * args.batch
@@ -295,6 +312,8 @@ def main():
             threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
             out["cpu_baseline"] = cpu_baseline(args.height, args.width, threads, timed=max(args.cpu_baseline_steps, 1))
         print(json.dumps(out))
+        if gate is not None and not gate["ok"]:
+            raise SystemExit(f"bench.py: first-step losses {gate['step0_losses']} are not the gated computation's (tests/golden/bench_step0_losses.json:{fkey})")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -460,3 +460,116 @@ extern "C" int cddmsl_roi_align_backward_pooled(const void* dy, const float* roi
   return roi_align_backward_impl(dy, rois, roi_start, dx, ws_ay, ws_ax, ws_fp, N, C, H, W, K, ph, pw, spatial_scale,
                                  sampling_ratio, aligned, dtype, 2, stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// torchvision.ops.roi_align as the reference calls it (layers/roi_align.py:58-65): input [N][C][H][W], rois [K][5] in ANY order
+// -> output [K][C][ph][pw]; backward: grad [K][C][ph][pw] -> grad_input [N][C][H][W].  The kernels above are channels-last and
+// the gather backward walks the RoIs of one image: these entry points re-lay the operands in caller-provided scratch (channels
+// zero-padded to whole 16-byte chunks, RoIs ranked stably by image for the backward) and call them -- same arithmetic, so the
+// results equal the channels-last entry points' element for element.
+namespace {
+template <typename T>
+__global__ void k_nchw_to_nhwc(const T* x, T* y, long N, int C, long HW, int Cp) {       // y [N][HW][Cp], pad channels zero
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * HW * Cp) return;
+  const int c = (int)(i % Cp);
+  const long p = (i / Cp) % HW, n = i / ((long)Cp * HW);
+  y[i] = c < C ? x[(n * C + c) * HW + p] : (T)0.f;
+}
+// out [K][C][HW] <- in [perm ? perm[k] : k][HW][Cp]   (perm: position of RoI k in the image-ranked order)
+template <typename T>
+__global__ void k_nhwc_to_nchw(const T* x, T* y, long K, int C, long HW, int Cp, const int* perm) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * C * HW) return;
+  const long p = i % HW, k = i / ((long)C * HW);
+  const int c = (int)((i / HW) % C);
+  const long ks = perm ? perm[k] : k;
+  y[i] = x[(ks * HW + p) * Cp + c];
+}
+// in [K][C][HW] (rows in the caller's order) -> out [rank[k]][HW][Cp]
+template <typename T>
+__global__ void k_nchw_rows_to_ranked_nhwc(const T* x, T* y, long K, int C, long HW, int Cp, const int* rank) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * HW * Cp) return;
+  const int c = (int)(i % Cp);
+  const long p = (i / Cp) % HW, k = i / ((long)Cp * HW);
+  y[((long)rank[k] * HW + p) * Cp + c] = c < C ? x[(k * C + c) * HW + p] : (T)0.f;
+}
+// stable rank of every RoI by image index (ties keep the caller's order), the ranked RoI list and roi_start [N+1].
+// K is a few thousand: one thread per RoI counting its predecessors is a fraction of the gather's time.
+__global__ void k_rank_rois(const float* rois, int* rank, float* sorted, int* roi_start, int K, int N) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k <= N) {                                    // roi_start[n] = number of RoIs of images < n (out-of-range images sort last)
+    int cnt = 0;
+    for (int j = 0; j < K; ++j) { const int b = (int)rois[5 * (long)j]; cnt += (b >= 0 && b < k) ? 1 : 0; }
+    roi_start[k] = cnt;
+  }
+  if (k >= K) return;
+  const int bk = (int)rois[5 * (long)k];
+  const long key = (bk >= 0 && bk < N) ? bk : N;
+  int r = 0;
+  for (int j = 0; j < K; ++j) {
+    const int bj = (int)rois[5 * (long)j];
+    const long kj = (bj >= 0 && bj < N) ? bj : N;
+    r += (kj < key || (kj == key && j < k)) ? 1 : 0;
+  }
+  rank[k] = r;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) sorted[5 * (long)r + q] = rois[5 * (long)k + q];
+}
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace
+
+extern "C" int cddmsl_roi_align_nchw_anyorder(const void* input, const float* rois, void* output, int N, int C, int H, int W, int K,
+                                              int ph, int pw, float spatial_scale, int sampling_ratio, int aligned, int dtype,
+                                              void* temp, size_t* temp_bytes, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !temp_bytes || N < 0 || C <= 0 || H <= 0 || W <= 0 || K < 0 || ph <= 0 || pw <= 0) return CDDMSL_ERR_ARG;
+  const int es = dtype == 0 ? 2 : 4, per = 16 / es;
+  const int Cp = (C + per - 1) / per * per;
+  const size_t o_x = 0, o_y = al256((size_t)N * H * W * Cp * es), total = o_y + al256((size_t)K * ph * pw * Cp * es);
+  if (!temp) { *temp_bytes = total; return CDDMSL_OK; }
+  if (*temp_bytes < total) return CDDMSL_ERR_ARG;
+  if (K == 0 || N == 0) return CDDMSL_OK;          // correctly-shaped empties (poolers.py:221-224): nothing to write
+  hipStream_t st = (hipStream_t)stream;
+  char* t = (char*)temp;
+  const long nx = (long)N * H * W * Cp, ny = (long)K * C * ph * pw;
+  if ((nx + 255) / 256 > 0x7fffffffL || (ny + 255) / 256 > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  if (dtype == 0) k_nchw_to_nhwc<__bf16><<<dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st>>>((const __bf16*)input, (__bf16*)(t + o_x), N, C, (long)H * W, Cp);
+  else k_nchw_to_nhwc<float><<<dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st>>>((const float*)input, (float*)(t + o_x), N, C, (long)H * W, Cp);
+  int rc = cddmsl_roi_align_forward(t + o_x, rois, t + o_y, nullptr, nullptr, N, Cp, H, W, K, ph, pw, spatial_scale, sampling_ratio, aligned, dtype, stream);
+  if (rc != CDDMSL_OK) return rc;
+  if (dtype == 0) k_nhwc_to_nchw<__bf16><<<dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, st>>>((const __bf16*)(t + o_y), (__bf16*)output, K, C, (long)ph * pw, Cp, nullptr);
+  else k_nhwc_to_nchw<float><<<dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, st>>>((const float*)(t + o_y), (float*)output, K, C, (long)ph * pw, Cp, nullptr);
+  return launch_status();
+}
+
+extern "C" int cddmsl_roi_align_backward_nchw_anyorder(const void* grad, const float* rois, void* grad_input, int N, int C, int H, int W,
+                                                       int K, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
+                                                       int dtype, void* temp, size_t* temp_bytes, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !temp_bytes || N < 0 || C <= 0 || H <= 0 || W <= 0 || K < 0 || ph <= 0 || pw <= 0) return CDDMSL_ERR_ARG;
+  const int es = dtype == 0 ? 2 : 4, per = 16 / es;
+  const int Cp = (C + per - 1) / per * per;
+  const size_t o_dy = 0, o_dx = o_dy + al256((size_t)K * ph * pw * Cp * es), o_ay = o_dx + al256((size_t)N * H * W * Cp * es),
+               o_ax = o_ay + al256((size_t)K * H * ph * 4), o_fp = o_ax + al256((size_t)K * W * pw * 4), o_rk = o_fp + al256((size_t)K * 16),
+               o_rs = o_rk + al256((size_t)K * 4), o_st = o_rs + al256((size_t)K * 20), total = o_st + al256((size_t)(N + 1) * 4);
+  if (!temp) { *temp_bytes = total; return CDDMSL_OK; }
+  if (*temp_bytes < total) return CDDMSL_ERR_ARG;
+  if (N == 0) return CDDMSL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  char* t = (char*)temp;
+  const long nd = (long)K * ph * pw * Cp, nx = (long)N * C * H * W;
+  if ((nd + 255) / 256 > 0x7fffffffL || (nx + 255) / 256 > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  const int nrk = (K > N + 1 ? K : N + 1);
+  k_rank_rois<<<dim3((unsigned)((nrk + 127) / 128)), dim3(128), 0, st>>>(rois, (int*)(t + o_rk), (float*)(t + o_rs), (int*)(t + o_st), K, N);
+  if (K > 0) {
+    if (dtype == 0) k_nchw_rows_to_ranked_nhwc<__bf16><<<dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st>>>((const __bf16*)grad, (__bf16*)(t + o_dy), K, C, (long)ph * pw, Cp, (const int*)(t + o_rk));
+    else k_nchw_rows_to_ranked_nhwc<float><<<dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, st>>>((const float*)grad, (float*)(t + o_dy), K, C, (long)ph * pw, Cp, (const int*)(t + o_rk));
+  }
+  // RoIs naming an image outside [0, N) rank last, past roi_start[N]: the gather never visits them (the forward writes zeros there)
+  int rc = cddmsl_roi_align_backward(t + o_dy, (const float*)(t + o_rs), (const int*)(t + o_st), t + o_dx, (float*)(t + o_ay), (float*)(t + o_ax),
+                                     (int*)(t + o_fp), N, Cp, H, W, K, ph, pw, spatial_scale, sampling_ratio, aligned, dtype, stream);
+  if (rc != CDDMSL_OK) return rc;
+  if (dtype == 0) k_nhwc_to_nchw<__bf16><<<dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st>>>((const __bf16*)(t + o_dx), (__bf16*)grad_input, N, C, (long)H * W, Cp, nullptr);
+  else k_nhwc_to_nchw<float><<<dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st>>>((const float*)(t + o_dx), (float*)grad_input, N, C, (long)H * W, Cp, nullptr);
+  return launch_status();
+}

@@ -48,6 +48,8 @@ def _L():
         L.cddmsl_roi_align_forward.argtypes = [vp] * 5 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_roi_align_backward.argtypes = [vp] * 7 + [ci] * 7 + [cf, ci, ci, ci, vp]
         L.cddmsl_nms_anyorder.argtypes = [vp] * 4 + [ci, cf, vp, vp, vp]
+        L.cddmsl_roi_align_nchw_anyorder.argtypes = [vp] * 3 + [ci] * 7 + [cf, ci, ci, ci, vp, vp, vp]
+        L.cddmsl_roi_align_backward_nchw_anyorder.argtypes = [vp] * 3 + [ci] * 7 + [cf, ci, ci, ci, vp, vp, vp]
         L.cddmsl_quantize_fp8.argtypes = [vp] * 4 + [c_long, ci, vp]
         L.cddmsl_conv_fwd_fp8.argtypes = [vp] * 7 + [ci] * 10 + [vp] * 4
         L.cddmsl_conv_fwd_q8.argtypes = [vp] * 7 + [ci] * 10 + [vp] * 4
@@ -623,6 +625,37 @@ def roi_align_backward(dy, rois, roi_start, in_shape, spatial_scale, sampling_ra
     fn = _L().cddmsl_roi_align_backward_pooled if pooled else _L().cddmsl_roi_align_backward
     check(fn(ptr(dy), ptr(rois), ptr(roi_start), ptr(dx), ptr(ay), ptr(ax), ptr(fp), N, C, H, W, K,
              ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(dy), stream_ptr()), "cddmsl_roi_align_backward")
+    return dx
+
+
+def roi_align_nchw(input, rois, output_size, spatial_scale, sampling_ratio, aligned):
+    """torchvision.ops.roi_align as layers/roi_align.py:58-65 calls it: input [N,C,H,W], rois [K,5] in any order -> [K,C,ph,pw]"""
+    require_cuda(input, rois)
+    assert rois.dim() == 2 and rois.size(1) == 5 and rois.dtype == torch.float32 and rois.is_contiguous() and input.is_contiguous()
+    N, C, H, W = input.shape
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    K = rois.shape[0]
+    out = torch.zeros((K, C, ph, pw), device=input.device, dtype=input.dtype)
+    nbytes = ctypes.c_size_t(0)
+    args = (N, C, H, W, K, ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(input))
+    check(_L().cddmsl_roi_align_nchw_anyorder(ptr(input), ptr(rois), ptr(out), *args, None, ctypes.byref(nbytes), stream_ptr()), "cddmsl_roi_align_nchw_anyorder(size)")
+    ws = workspace("roi_nchw", max(nbytes.value, 1), input.device)
+    check(_L().cddmsl_roi_align_nchw_anyorder(ptr(input), ptr(rois), ptr(out), *args, ptr(ws), ctypes.byref(nbytes), stream_ptr()), "cddmsl_roi_align_nchw_anyorder")
+    return out
+
+
+def roi_align_backward_nchw(grad, rois, input_shape, spatial_scale, sampling_ratio, aligned):
+    """its backward: grad [K,C,ph,pw] -> grad_input [N,C,H,W]"""
+    require_cuda(grad, rois)
+    assert rois.dtype == torch.float32 and rois.is_contiguous() and grad.is_contiguous()
+    N, C, H, W = input_shape
+    K, _, ph, pw = grad.shape
+    dx = torch.zeros(tuple(input_shape), device=grad.device, dtype=grad.dtype)
+    nbytes = ctypes.c_size_t(0)
+    args = (N, C, H, W, K, ph, pw, spatial_scale, sampling_ratio, int(aligned), _dt(grad))
+    check(_L().cddmsl_roi_align_backward_nchw_anyorder(ptr(grad), ptr(rois), ptr(dx), *args, None, ctypes.byref(nbytes), stream_ptr()), "cddmsl_roi_align_backward_nchw_anyorder(size)")
+    ws = workspace("roi_nchw_b", max(nbytes.value, 1), grad.device)
+    check(_L().cddmsl_roi_align_backward_nchw_anyorder(ptr(grad), ptr(rois), ptr(dx), *args, ptr(ws), ctypes.byref(nbytes), stream_ptr()), "cddmsl_roi_align_backward_nchw_anyorder")
     return dx
 
 

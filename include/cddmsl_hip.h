@@ -118,6 +118,18 @@ int cddmsl_roi_align_forward_affine(const void* x, const float* rois, void* y, v
 int cddmsl_roi_align_backward_pooled(const void* dy, const float* rois, const int* roi_start, void* dx, float* ws_ay,
                                      float* ws_ax, int* ws_fp, int N, int C, int H, int W, int K, int ph, int pw,
                                      float spatial_scale, int sampling_ratio, int aligned, int dtype, void* stream);
+/* torchvision.ops.roi_align with the signature the reference calls (layers/roi_align.py:58-65 -> roi_align(input, rois, output_size,
+ * spatial_scale, sampling_ratio, aligned)): input [N][C][H][W] (NCHW, any C), rois [K][5] (batch_idx, x0, y0, x1, y1) in ANY order ->
+ * output [K][C][ph][pw]; backward: grad [K][C][ph][pw] -> grad_input [N][C][H][W] (what torchvision's autograd Function hands back).
+ * They re-lay the operands channels-last in caller-provided scratch (RoIs ranked stably by image for the gather backward) and run
+ * the kernels above: same arithmetic.  Call with temp == NULL to get *temp_bytes.  The training path keeps the channels-last,
+ * grouped-by-image entry points (poolers.py:68-95 emits RoIs in that order anyway). */
+int cddmsl_roi_align_nchw_anyorder(const void* input, const float* rois, void* output, int N, int C, int H, int W, int K, int ph, int pw,
+                                   float spatial_scale, int sampling_ratio, int aligned, int dtype, void* temp, size_t* temp_bytes,
+                                   void* stream);
+int cddmsl_roi_align_backward_nchw_anyorder(const void* grad, const float* rois, void* grad_input, int N, int C, int H, int W, int K,
+                                            int ph, int pw, float spatial_scale, int sampling_ratio, int aligned, int dtype, void* temp,
+                                            size_t* temp_bytes, void* stream);
 
 /* ---- RPN / matcher index stages --------------------------------------------------------------------------------
  * modeling/anchor_generator.py:161-228, modeling/box_regression.py:77-115, modeling/proposal_generator/rpn.py:514-533,

@@ -635,3 +635,56 @@ def test_nms_with_the_torchvision_signature():
         assert n == len(want) and torch.equal(keep[:n].cpu(), want) and bool((keep[n:] == -1).all())
     keep, nkeep = hip.nms_anyorder(torch.zeros(0, 4).cuda(), torch.zeros(0).cuda(), 0.5)
     assert int(nkeep) == 0 and keep.numel() == 0
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
+def test_roi_align_with_the_torchvision_signature(dtype, tol):
+    """cddmsl_roi_align_nchw_anyorder / _backward_nchw_anyorder: ``torchvision.ops.roi_align(input[N,C,H,W], rois[K,5], ...)`` as
+    layers/roi_align.py:58-65 calls it -- NCHW, RoIs in ANY order (here shuffled across images, one naming an image outside the
+    batch, one empty box), a channel count that is not a whole 16-byte chunk -- against the oracle, forward and backward; and the
+    reference's own 5x5 known-answer table (tests/layers/test_roi_align.py:14-47) with its single channel."""
+    from cddmsl_amd import hip
+    from oracle import ops as oo
+    k = json.load(open(os.path.join(G, "kat.json")))["roi_align_5x5"]
+    x5 = torch.arange(25, dtype=torch.float32).reshape(1, 1, 5, 5).cuda().to(dtype)
+    r5 = T([[0.0] + [float(v) for v in k["box"]]]).cuda()
+    for aligned in (False, True):
+        out = hip.roi_align_nchw(x5, r5, (4, 4), 1.0, 0, aligned)
+        assert out.shape == (1, 1, 4, 4)
+        assert torch.allclose(out[0, 0].float().cpu(), T(k["aligned_true" if aligned else "aligned_false"]), atol=0.1 if dtype == torch.bfloat16 else 1e-5)
+    N, C, H, W, K = 3, 37, 13, 21, 41
+    g = torch.Generator().manual_seed(11)
+    x = _rand((N, C, H, W), 1).to(dtype).float()
+    b = torch.randint(0, N, (K,), generator=g)                                   # NOT grouped by image
+    x0 = torch.rand(K, generator=g) * W * 16 * 0.9 - 10
+    y0 = torch.rand(K, generator=g) * H * 16 * 0.9 - 10
+    rois = torch.stack([b.float(), x0, y0, x0 + torch.rand(K, generator=g) * W * 12, y0 + torch.rand(K, generator=g) * H * 12], 1)
+    rois[5, 3:] = rois[5, 1:3]                                                   # empty box
+    assert not torch.equal(torch.sort(b).values, b)
+    xr = x.clone().requires_grad_(True)
+    ref = oo.roi_align(xr, rois, 14, 1 / 16, 0, True)
+    dy = _rand(tuple(ref.shape), 3).to(dtype).float()
+    ref.backward(dy)
+    out = hip.roi_align_nchw(x.cuda().to(dtype), rois.cuda(), 14, 1 / 16, 0, True)
+    assert out.shape == (K, C, 14, 14)
+    assert (out.float().cpu() - ref.detach()).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    dx = hip.roi_align_backward_nchw(dy.cuda().to(dtype), rois.cuda(), (N, C, H, W), 1 / 16, 0, True)
+    assert dx.shape == (N, C, H, W)
+    assert (dx.float().cpu() - xr.grad).abs().max() < tol * max(1.0, float(xr.grad.abs().max()))
+    # equal, element for element, to the channels-last entry points on the image-sorted RoIs
+    order = torch.sort(b, stable=True).indices
+    srt = rois[order].contiguous()
+    y_cl = hip.roi_align_forward(_nhwc(torch.nn.functional.pad(x, (0, 0, 0, 0, 0, 3))).cuda().to(dtype), srt.cuda(), 14, 14, 1 / 16, 0, True)
+    assert torch.equal(out[order.cuda()], y_cl.permute(0, 3, 1, 2)[:, :C])
+    # a RoI naming an image outside the batch: zeros forward, ignored backward; K = 0: shaped empties
+    bad = rois.clone()
+    bad[7, 0] = 9.0
+    ob = hip.roi_align_nchw(x.cuda().to(dtype), bad.cuda(), 14, 1 / 16, 0, True)
+    assert (ob[7] == 0).all() and torch.equal(ob[8:], out[8:]) and torch.equal(ob[:7], out[:7])
+    dy_z = dy.clone()
+    dy_z[7] = 0
+    dxb = hip.roi_align_backward_nchw(dy.cuda().to(dtype), bad.cuda(), (N, C, H, W), 1 / 16, 0, True)
+    dxz = hip.roi_align_backward_nchw(dy_z.cuda().to(dtype), rois.cuda(), (N, C, H, W), 1 / 16, 0, True)
+    assert torch.equal(dxb, dxz)
+    assert hip.roi_align_nchw(x.cuda().to(dtype), torch.zeros(0, 5).cuda(), 14, 1 / 16, 0, True).shape == (0, C, 14, 14)
+    assert (hip.roi_align_backward_nchw(torch.zeros(0, C, 14, 14, dtype=dtype).cuda(), torch.zeros(0, 5).cuda(), (N, C, H, W), 1 / 16, 0, True) == 0).all()
