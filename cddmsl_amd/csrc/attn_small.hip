@@ -306,3 +306,144 @@ extern "C" int cddmsl_attn_small_bwd(const void* q, const void* k, const void* v
   hipLaunchKernelGGL(k_attn_small_bwd, dim3((unsigned)(nseq * heads)), dim3(192), 0, (hipStream_t)stream, a);
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The mapper's LAST layer for the last token only (``v2l`` keeps one of the 80 mapped tokens, clipcap.py:714-719; the layer is
+// clipcap.py:59-83 with a single query row): per (sequence, head)  p = softmax(q . K^T * scale) over the t keys, o = p . V.
+// One wave per (sequence, head); f32 arithmetic on bf16 operands.  q [n][ldq], kv [n*t][ldkv] with K of head h at column h*dh and
+// V at column voff + h*dh (the to_keys_values projection as it comes), o [n][ldo]; p [n][heads][t] f32 is kept for the backward:
+//     dp = do . V^T,  ds = p o (dp - sum p dp) * scale,  dq = ds . K,  dK[j] = ds[j] q,  dV[j] = p[j] do.
+namespace {
+constexpr int ALT = 128;       // most keys per sequence
+constexpr int ALD = 128;       // largest head dim
+
+struct LastArgs {
+  const char *q, *kv, *dout;
+  float* p;
+  char *o, *dq, *dkv;
+  int n, t, heads, dh, ldq, ldkv, voff, ldo;
+  float scale;
+};
+
+__device__ __forceinline__ float ldbf(const char* base, long idx) { return bf2f(((const unsigned short*)base)[idx]); }
+
+__global__ __launch_bounds__(64) void k_attn_last_fwd(LastArgs a) {
+  __shared__ float sq[ALD], sp[ALT];
+  const int lane = threadIdx.x, s = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+  const char* kvb = a.kv + ((long)s * a.t * a.ldkv + h * a.dh) * 2;
+  for (int c = lane; c < a.dh; c += 64) sq[c] = ldbf(a.q, (long)s * a.ldq + h * a.dh + c);
+  __syncthreads();
+  float sc[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = lane + 64 * u;
+    if (j < a.t) {
+      const u32x4* row = (const u32x4*)(kvb + (long)j * a.ldkv * 2);
+      float acc = 0.f;
+      for (int c8 = 0; c8 < a.dh / 8; ++c8) {
+        const u32x4 v = row[c8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc = __builtin_fmaf(sq[c8 * 8 + 2 * e], bf2f(v[e] & 0xffff), acc);
+          acc = __builtin_fmaf(sq[c8 * 8 + 2 * e + 1], bf2f(v[e] >> 16), acc);
+        }
+      }
+      sc[u] = acc * a.scale;
+    }
+  }
+  const float m = wave_max(fmaxf(sc[0], sc[1]));
+  float e0 = (lane < a.t) ? __expf(sc[0] - m) : 0.f, e1 = (lane + 64 < a.t) ? __expf(sc[1] - m) : 0.f;
+  const float inv = 1.0f / wave_sum(e0 + e1);
+  e0 *= inv; e1 *= inv;
+  float* pp = a.p + ((long)s * a.heads + h) * a.t;
+  if (lane < a.t) { sp[lane] = e0; pp[lane] = e0; }
+  if (lane + 64 < a.t) { sp[lane + 64] = e1; pp[lane + 64] = e1; }
+  __syncthreads();
+  if (2 * lane < a.dh) {
+    const char* vb = kvb + a.voff * 2 + lane * 4;
+    float o0 = 0.f, o1 = 0.f;
+    for (int j = 0; j < a.t; ++j) {
+      const unsigned v = *(const unsigned*)(vb + (long)j * a.ldkv * 2);
+      o0 = __builtin_fmaf(sp[j], bf2f(v & 0xffff), o0);
+      o1 = __builtin_fmaf(sp[j], bf2f(v >> 16), o1);
+    }
+    *(unsigned*)(a.o + ((long)s * a.ldo + h * a.dh + 2 * lane) * 2) = pack2bf(o0, o1);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_attn_last_bwd(LastArgs a) {
+  __shared__ float sq[ALD], sdo[ALD], sp[ALT], sds[ALT];
+  const int lane = threadIdx.x, s = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+  const char* kvb = a.kv + ((long)s * a.t * a.ldkv + h * a.dh) * 2;
+  char* dkvb = a.dkv + ((long)s * a.t * a.ldkv + h * a.dh) * 2;
+  const float* pp = a.p + ((long)s * a.heads + h) * a.t;
+  for (int c = lane; c < a.dh; c += 64) {
+    sq[c] = ldbf(a.q, (long)s * a.ldq + h * a.dh + c);
+    sdo[c] = ldbf(a.dout, (long)s * a.ldo + h * a.dh + c);
+  }
+  for (int j = lane; j < a.t; j += 64) sp[j] = pp[j];
+  __syncthreads();
+  float dp[2] = {0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = lane + 64 * u;
+    if (j < a.t) {
+      const u32x4* row = (const u32x4*)(kvb + a.voff * 2 + (long)j * a.ldkv * 2);
+      float acc = 0.f;
+      for (int c8 = 0; c8 < a.dh / 8; ++c8) {
+        const u32x4 v = row[c8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc = __builtin_fmaf(sdo[c8 * 8 + 2 * e], bf2f(v[e] & 0xffff), acc);
+          acc = __builtin_fmaf(sdo[c8 * 8 + 2 * e + 1], bf2f(v[e] >> 16), acc);
+        }
+      }
+      dp[u] = acc;
+    }
+  }
+  const float p0 = lane < a.t ? sp[lane] : 0.f, p1 = lane + 64 < a.t ? sp[lane + 64] : 0.f;
+  const float dot = wave_sum(p0 * dp[0] + p1 * dp[1]);
+  if (lane < a.t) sds[lane] = p0 * (dp[0] - dot) * a.scale;
+  if (lane + 64 < a.t) sds[lane + 64] = p1 * (dp[1] - dot) * a.scale;
+  __syncthreads();
+  if (2 * lane < a.dh) {
+    const float q0 = sq[2 * lane], q1 = sq[2 * lane + 1], g0 = sdo[2 * lane], g1 = sdo[2 * lane + 1];
+    float dq0 = 0.f, dq1 = 0.f;
+    for (int j = 0; j < a.t; ++j) {
+      const long ro = (long)j * a.ldkv * 2 + lane * 4;
+      const unsigned kk = *(const unsigned*)(kvb + ro);
+      const float ds = sds[j], pj = sp[j];
+      dq0 = __builtin_fmaf(ds, bf2f(kk & 0xffff), dq0);
+      dq1 = __builtin_fmaf(ds, bf2f(kk >> 16), dq1);
+      *(unsigned*)(dkvb + ro) = pack2bf(ds * q0, ds * q1);
+      *(unsigned*)(dkvb + a.voff * 2 + ro) = pack2bf(pj * g0, pj * g1);
+    }
+    *(unsigned*)(a.dq + ((long)s * a.ldq + h * a.dh + 2 * lane) * 2) = pack2bf(dq0, dq1);
+  }
+}
+
+int check_last(const LastArgs& a, int dtype) {
+  if (dtype != 0 || a.n < 0 || a.t <= 0 || a.t > ALT || a.heads <= 0 || a.dh <= 0 || a.dh > ALD || (a.dh & 7)) return CDDMSL_ERR_ARG;
+  if ((a.ldq | a.ldkv | a.voff | a.ldo) & 7) return CDDMSL_ERR_ARG;      // 16-byte rows / column blocks
+  if ((long)a.n * a.heads > 0x7fffffffL) return CDDMSL_ERR_ARG;
+  return CDDMSL_OK;
+}
+}  // namespace
+
+extern "C" int cddmsl_attn_last_fwd(const void* q, const void* kv, void* o, float* p, int n, int t, int heads, int dh, int ldq, int ldkv,
+                                    int voff, int ldo, float scale, int dtype, void* stream) {
+  LastArgs a{(const char*)q, (const char*)kv, nullptr, p, (char*)o, nullptr, nullptr, n, t, heads, dh, ldq, ldkv, voff, ldo, scale};
+  if (int e = check_last(a, dtype)) return e;
+  if (n == 0) return CDDMSL_OK;
+  hipLaunchKernelGGL(k_attn_last_fwd, dim3((unsigned)(n * heads)), dim3(64), 0, (hipStream_t)stream, a);
+  return launch_status();
+}
+
+extern "C" int cddmsl_attn_last_bwd(const void* q, const void* kv, const void* dout, const float* p, void* dq, void* dkv, int n, int t,
+                                    int heads, int dh, int ldq, int ldkv, int voff, int ldo, float scale, int dtype, void* stream) {
+  LastArgs a{(const char*)q, (const char*)kv, (const char*)dout, (float*)p, nullptr, (char*)dq, (char*)dkv, n, t, heads, dh, ldq, ldkv, voff, ldo, scale};
+  if (int e = check_last(a, dtype)) return e;
+  if (n == 0) return CDDMSL_OK;
+  hipLaunchKernelGGL(k_attn_last_bwd, dim3((unsigned)(n * heads)), dim3(64), 0, (hipStream_t)stream, a);
+  return launch_status();
+}

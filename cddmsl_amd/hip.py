@@ -72,6 +72,8 @@ def _L():
         L.cddmsl_focal_ce_bwd.argtypes = [vp] * 5 + [c_long, ci, cf, ci, cf, vp]
         L.cddmsl_attn_small_fwd.argtypes = [vp] * 4 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_attn_small_bwd.argtypes = [vp] * 7 + [ci] * 8 + [cf, ci, vp]
+        L.cddmsl_attn_last_fwd.argtypes = [vp] * 4 + [ci] * 8 + [cf, ci, vp]
+        L.cddmsl_attn_last_bwd.argtypes = [vp] * 6 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_contrastive_fwd.argtypes = [vp] * 4 + [ci, ci, vp]
         L.cddmsl_contrastive_bwd.argtypes = [vp] * 5 + [ci, ci, vp]
         _sigs_done = True
@@ -909,6 +911,32 @@ def attn_small_fwd(q, kv, t, heads, scale):
     check(_L().cddmsl_attn_small_fwd(ptr(q), ptr(kv), vptr, ptr(o), n, t, heads, dh, d, 2 * d, 2 * d, d, float(scale), 0, stream_ptr()),
           "cddmsl_attn_small_fwd")
     return o
+
+
+@_timed("attn_last")
+def attn_last_fwd(q, kv, t, heads, scale):
+    """one query row per sequence: q [n, d], kv [n*t, 2d] (keys | values) bf16 -> (o [n, d] bf16, p [n, heads, t] f32)"""
+    require_cuda(q, kv)
+    n, d = q.shape
+    assert q.dtype == kv.dtype == torch.bfloat16 and q.is_contiguous() and kv.is_contiguous() and tuple(kv.shape) == (n * t, 2 * d)
+    o = torch.empty((n, d), device=q.device, dtype=q.dtype)
+    p = torch.empty((n, heads, t), device=q.device, dtype=torch.float32)
+    check(_L().cddmsl_attn_last_fwd(ptr(q), ptr(kv), ptr(o), ptr(p), n, t, heads, d // heads, d, 2 * d, d, d, float(scale), 0, stream_ptr()),
+          "cddmsl_attn_last_fwd")
+    return o, p
+
+
+@_timed("attn_last")
+def attn_last_bwd(q, kv, do, p, t, heads, scale):
+    """-> (dq [n, d], dkv [n*t, 2d]) bf16"""
+    require_cuda(q, kv, do, p)
+    n, d = q.shape
+    do = do.contiguous()
+    assert do.shape == (n, d) and do.dtype == q.dtype and p.is_contiguous()
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    check(_L().cddmsl_attn_last_bwd(ptr(q), ptr(kv), ptr(do), ptr(p), ptr(dq), ptr(dkv), n, t, heads, d // heads, d, 2 * d, d, d, float(scale), 0,
+                                    stream_ptr()), "cddmsl_attn_last_bwd")
+    return dq, dkv
 
 
 @_timed("attn_small")

@@ -1070,6 +1070,29 @@ def small_attention(q, kv, t, heads, scale):
     return SmallAttnFn.apply(q, kv, t, heads, scale)
 
 
+class LastTokenAttnFn(torch.autograd.Function):
+    """softmax(q K^T * scale) V for ONE query row per sequence (the mapper's last layer, evaluated for the token ``v2l`` keeps):
+    q [n, d], kv [n*t, 2d] bf16 as the projections emit them -> o [n, d]; one kernel per direction instead of ~14 torch ops."""
+
+    @staticmethod
+    def forward(ctx, q, kv, t, heads, scale):
+        o, p = hip.attn_last_fwd(q, kv, t, heads, scale)
+        ctx.save_for_backward(q, kv, p)
+        ctx.cfg = (t, heads, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, p = ctx.saved_tensors
+        t, heads, scale = ctx.cfg
+        dq, dkv = hip.attn_last_bwd(q, kv, do.to(q.dtype), p, t, heads, scale)
+        return dq, dkv, None, None, None
+
+
+def last_token_attention(q, kv, t, heads, scale):
+    return LastTokenAttnFn.apply(q.contiguous(), kv.contiguous(), t, heads, scale)
+
+
 class SmallAttnQkvFn(torch.autograd.Function):
     """The same on the output of ONE fused q|k|v projection [n*t, 3d]: the backward hands back one [n*t, 3d] gradient, so
     the projection's input gradient is one GEMM and no add of two partial gradients."""

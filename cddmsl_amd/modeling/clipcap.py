@@ -134,6 +134,14 @@ class TransformerMapper(nn.Module):
         a = lyr.attn
         H, dh = a.num_heads, d // a.num_heads
         y = layers.layer_norm(h.reshape(n * t, d), lyr.norm1.weight, lyr.norm1.bias, T)           # all tokens: keys / values
+        if T == torch.bfloat16 and dh % 8 == 0 and dh <= 128 and t <= 128 and a.to_keys_values.bias is None:
+            # throughput path: both projections emit bf16, the one-query attention is one kernel per direction
+            kv = a.to_keys_values(y, out_f32=False)                                                # [n*t, 2d]: keys | values
+            q = a.to_queries(y.view(n, t, d)[:, -1].contiguous(), out_f32=False)                   # the one query row [n, d]
+            o = layers.last_token_attention(q, kv, t, H, a.scale)
+            hl = a.project(o, residual=h[:, -1].contiguous())                                      # (the f32 residual add rides in the epilogue)
+            y = layers.layer_norm(hl, lyr.norm2.weight, lyr.norm2.bias, T)
+            return lyr.mlp(y, hl)
         kv = a.to_keys_values(y).view(n, t, 2, H, dh)
         q = a.to_queries(y.view(n, t, d)[:, -1].contiguous()).view(n, H, 1, dh)                   # the one query row
         k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)                   # [n, H, t, dh] f32

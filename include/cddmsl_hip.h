@@ -183,6 +183,14 @@ int cddmsl_attn_small_fwd(const void* q, const void* k, const void* v, void* o, 
                           int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
 int cddmsl_attn_small_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, void* dk, void* dv, int nseq,
                           int t, int heads, int dh, int ldq, int ldk, int ldv, int ldo, float scale, int dtype, void* stream);
+/* the mapper's LAST layer evaluated for the last token only (v2l keeps one of the mapped tokens, clipcap.py:714-719; attention of
+ * clipcap.py:59-83 with ONE query row per sequence): p [n][heads][t] f32 = softmax(q . K^T * scale), o [n][ldo] = p . V.  q [n][ldq],
+ * kv [n*t][ldkv] bf16 with K of head h at column h*dh and V at column voff + h*dh; bf16 only (dtype 0), t <= 128, dh <= 128, dh % 8 == 0.
+ * Backward: dq [n][ldq], dkv [n*t][ldkv] (every element written) from dout [n][ldo] and the saved p. */
+int cddmsl_attn_last_fwd(const void* q, const void* kv, void* o, float* p, int n, int t, int heads, int dh, int ldq, int ldkv, int voff,
+                         int ldo, float scale, int dtype, void* stream);
+int cddmsl_attn_last_bwd(const void* q, const void* kv, const void* dout, const float* p, void* dq, void* dkv, int n, int t, int heads,
+                         int dh, int ldq, int ldkv, int voff, int ldo, float scale, int dtype, void* stream);
 
 /* ---- fp32 heads: cosine-logit classifier (modeling/roi_heads/fast_rcnn.py:546-572) and the contrastive loss over
  * the cosine-similarity matrix (modeling/meta_arch/rcnn.py:308-317,458-468) ------------------------------------ */

@@ -688,3 +688,27 @@ def test_roi_align_with_the_torchvision_signature(dtype, tol):
     assert torch.equal(dxb, dxz)
     assert hip.roi_align_nchw(x.cuda().to(dtype), torch.zeros(0, 5).cuda(), 14, 1 / 16, 0, True).shape == (0, C, 14, 14)
     assert (hip.roi_align_backward_nchw(torch.zeros(0, C, 14, 14, dtype=dtype).cuda(), torch.zeros(0, 5).cuda(), (N, C, H, W), 1 / 16, 0, True) == 0).all()
+
+
+@pytest.mark.parametrize("n,t,H,dh", [(5, 80, 8, 96), (3, 37, 4, 64), (2, 128, 2, 128)])
+def test_last_token_attention_fwd_bwd(n, t, H, dh):
+    """cddmsl_attn_last_fwd/bwd (the mapper's last layer for the one token v2l keeps, clipcap.py:59-83,714-719): one query row per
+    sequence against fp32 torch attention on the same bf16 operands, forward and the three gradients."""
+    from cddmsl_amd import layers
+    d = H * dh
+    q = (_rand((n, d), 1) * 0.5).bfloat16().cuda().requires_grad_(True)
+    kv = (_rand((n * t, 2 * d), 2) * 0.5).bfloat16().cuda().requires_grad_(True)
+    scale = dh ** -0.5
+    o = layers.last_token_attention(q, kv, t, H, scale)
+    do = _rand((n, d), 3).bfloat16().cuda()
+    o.backward(do)
+    qf = q.detach().float().requires_grad_(True)
+    kvf = kv.detach().float().requires_grad_(True)
+    k4 = kvf.view(n, t, 2, H, dh)
+    k, v = k4[:, :, 0].permute(0, 2, 1, 3), k4[:, :, 1].permute(0, 2, 1, 3)
+    att = torch.softmax((qf.view(n, H, 1, dh) * k).sum(-1) * scale, dim=-1)
+    ref = (att.unsqueeze(-1) * v).sum(2).reshape(n, d)
+    ref.backward(do.float())
+    assert o.dtype == torch.bfloat16 and (o.float() - ref).abs().max() <= 1e-2 * ref.abs().max()
+    assert (q.grad.float() - qf.grad).abs().max() <= 1.5e-2 * qf.grad.abs().max()
+    assert (kv.grad.float() - kvf.grad).abs().max() <= 1.5e-2 * kvf.grad.abs().max()
