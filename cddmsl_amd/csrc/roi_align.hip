@@ -230,6 +230,157 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char*
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Throughput (bf16) forward: every feature pixel a bin row needs is loaded ONCE.
+//
+// k_roi_align_fwd above walks (bin, sample, 4 taps): 4 * gh * gw loads of a pixel's channel chunk per bin.  On the training
+// workload the sampled RoIs average 8.8 x 9.4 feature pixels (tools: scratch profile of round 3), i.e. bins of ~0.65 pixel: the
+// 14 bins of a row re-read the same ~11 pixel columns 56+ times, and tap loads + per-sample table reads were ~90 % of the kernel
+// (round-2 ablation).  Bilinear weights are separable and the row weights do not depend on the x sample, so for one bin row
+//     R[px]      = sum over the row's y samples of (wy_lo x[y_lo][px] + wy_hi x[y_hi][px])     (duplicate rows merged)
+//     bin j      = 1/count * sum over its x samples of (wx_lo R[x_lo] + wx_hi R[x_hi])
+// and x_lo never decreases along the row: the wave keeps R[cur], R[cur+1] in registers and slides.  One wave = one bin row (RP = 1)
+// or one POOLED row = two bin rows folded at half weight (RP = 2: the 2x2-average-pooled crops only) x 64 channel chunks; all
+// addresses and weights are wave-uniform (LDS tables, readfirstlane).  Same sums in another order: the bf16 results differ from
+// k_roi_align_fwd's by rounding; the exact-f32 instantiation keeps the reference's expression order.
+constexpr int ROW_MAXY = 32;       // merged feature rows per bin row pair held in LDS
+template <int RP>
+__global__ __launch_bounds__(256) void k_roi_align_fwd_rows(const char* x, const float* rois, char* y, int N, int H, int W, int cch, int ph, int pw,
+                                                            float scale, int sampling_ratio, int aligned, const float* esc, const float* ebi, int relu) {
+  const int nrb = ph / RP;
+  const int i0 = (blockIdx.x % nrb) * RP, k = blockIdx.x / nrb;
+  const RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
+  __shared__ int s_xl[ROI_MAXS], s_py[ROW_MAXY], s_n[2];
+  __shared__ float s_xwl[ROI_MAXS], s_xwh[ROI_MAXS], s_wy[ROW_MAXY];
+  __shared__ int s_ylo[ROW_MAXY], s_yhi[ROW_MAXY];
+  __shared__ float s_ywl[ROW_MAXY], s_ywh[ROW_MAXY];
+  const int ny = RP * g.gh, nx = pw * g.gw;                    // y samples of this (pooled) row; x samples of the whole row
+  const int opw = pw / RP;                                     // outputs per row
+  const int c = threadIdx.x;                                   // channel chunk of this lane
+  const bool inb = g.b >= 0 && g.b < N;
+  if (nx > ROI_MAXS || 2 * ny > ROW_MAXY) {                    // a sampling grid beyond the tables (block-uniform): bins evaluated tap by tap
+    if (c >= cch) return;
+    const u32x4* xb = (const u32x4*)x + (long)(inb ? g.b : 0) * H * W * cch + c;
+    const float inv = 1.0f / ((float)max(g.gh * g.gw, 1) * (float)(RP * RP));
+    for (int jo = 0; jo < opw; ++jo) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int rr = 0; rr < RP && inb; ++rr)
+        for (int cc = 0; cc < RP; ++cc)
+          for (int iy = 0; iy < g.gh; ++iy) {
+            int yl, yh; float wyl, wyh;
+            const float yy = g.y0 + (float)(i0 + rr) * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
+            if (!axis_tap(yy, H, yl, yh, wyl, wyh)) continue;
+            for (int ix = 0; ix < g.gw; ++ix) {
+              int xl, xh; float wxl, wxh;
+              const float xx = g.x0 + (float)(jo * RP + cc) * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+              if (!axis_tap(xx, W, xl, xh, wxl, wxh)) continue;
+              float v1[8], v2[8], v3[8], v4[8];
+              Vec<__bf16>::unpack(xb[((long)yl * W + xl) * cch], v1); Vec<__bf16>::unpack(xb[((long)yl * W + xh) * cch], v2);
+              Vec<__bf16>::unpack(xb[((long)yh * W + xl) * cch], v3); Vec<__bf16>::unpack(xb[((long)yh * W + xh) * cch], v4);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) acc[q] += wyl * (wxl * v1[q] + wxh * v2[q]) + wyh * (wxl * v3[q] + wxh * v4[q]);
+            }
+          }
+      float o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        o[q] = acc[q] * inv;
+        if (esc) { o[q] = __builtin_fmaf(o[q], esc[c * 8 + q], ebi[c * 8 + q]); if (relu) o[q] = fmaxf(o[q], 0.f); }
+      }
+      ((u32x4*)y)[(((long)k * nrb + i0 / RP) * opw + jo) * cch + c] = Vec<__bf16>::pack(o);
+    }
+    return;
+  }
+  for (int s = threadIdx.x; s < ny + nx; s += blockDim.x) {
+    int lo = -1, hi = -1; float wl = 0.f, wh = 0.f;
+    if (s < ny) {
+      const int rr = s / g.gh, iy = s - rr * g.gh;
+      const float yy = g.y0 + (float)(i0 + rr) * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
+      if (!axis_tap(yy, H, lo, hi, wl, wh)) lo = -1;
+      s_ylo[s] = lo; s_yhi[s] = hi; s_ywl[s] = wl; s_ywh[s] = wh;
+    } else {
+      const int sx = s - ny, j = sx / g.gw, ix = sx - j * g.gw;
+      const float xx = g.x0 + (float)j * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+      if (!axis_tap(xx, W, lo, hi, wl, wh)) lo = -1;
+      s_xl[sx] = lo; s_xwl[sx] = wl; s_xwh[sx] = wh;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                                      // merge the y taps by feature row (samples ascend: rows repeat back to back)
+    int n = 0;
+    for (int s = 0; s < ny; ++s) {
+      if (s_ylo[s] < 0) continue;
+      const int r2[2] = {s_ylo[s], s_yhi[s]};
+      const float w2[2] = {s_ywl[s], s_ywh[s]};
+      for (int e = 0; e < 2; ++e) {
+        int f = -1;
+        for (int q = 0; q < n; ++q) if (s_py[q] == r2[e]) f = q;
+        if (f < 0) { f = n++; s_py[f] = r2[e]; s_wy[f] = 0.f; }
+        s_wy[f] += w2[e];
+      }
+    }
+    int first = -1;
+    for (int s = 0; s < nx && first < 0; ++s) if (s_xl[s] >= 0) first = s_xl[s];
+    s_n[0] = n; s_n[1] = first;
+  }
+  __syncthreads();
+  if (c >= cch) return;
+  const int nrow = __builtin_amdgcn_readfirstlane(s_n[0]);
+  const int first = __builtin_amdgcn_readfirstlane(s_n[1]);
+  const float inv = 1.0f / ((float)max(g.gh * g.gw, 1) * (float)(RP * RP));
+  float sq[8], bq[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { sq[q] = esc ? esc[c * 8 + q] : 1.f; bq[q] = ebi ? ebi[c * 8 + q] : 0.f; }
+  const u32x4* xb = (const u32x4*)x + (long)(inb ? g.b : 0) * H * W * cch + c;
+  auto rload = [&](int px, float* R) {                         // R = sum over the merged rows of wy * x[py][px]   (wave-uniform px)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) R[q] = 0.f;
+    for (int e = 0; e < nrow; ++e) {
+      const int py = __builtin_amdgcn_readfirstlane(s_py[e]);
+      const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_wy[e])));
+      float v[8];
+      Vec<__bf16>::unpack(xb[((long)py * W + px) * cch], v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) R[q] = __builtin_fmaf(wy, v[q], R[q]);
+    }
+  };
+  float R0[8], R1[8], acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { R0[q] = R1[q] = acc[q] = 0.f; }
+  int cur = first;
+  const bool any = inb && nrow > 0 && first >= 0;
+  if (any) { rload(cur, R0); rload(min(cur + 1, W - 1), R1); }
+  const int spo = RP * g.gw;                                   // x samples per output
+  u32x4* yo = (u32x4*)y + ((long)k * nrb + i0 / RP) * opw * cch + c;
+  int left = spo, j = 0;
+  for (int s = 0; s < nx; ++s) {
+    const int xl = __builtin_amdgcn_readfirstlane(s_xl[s]);
+    if (any && xl >= 0) {
+      while (cur < xl) {                                       // slide: x_lo never decreases along the row
+        ++cur;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) R0[q] = R1[q];
+        rload(min(cur + 1, W - 1), R1);
+      }
+      const float wl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_xwl[s])));
+      const float wh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_xwh[s])));
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = __builtin_fmaf(wl, R0[q], __builtin_fmaf(wh, R1[q], acc[q]));
+    }
+    if (--left == 0) {
+      float o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        o[q] = acc[q] * inv;
+        if (esc) { o[q] = __builtin_fmaf(o[q], sq[q], bq[q]); if (relu) o[q] = fmaxf(o[q], 0.f); }
+        acc[q] = 0.f;
+      }
+      yo[(long)j * cch] = Vec<__bf16>::pack(o);
+      ++j; left = spo;
+    }
+  }
+}
+
 // Per-RoI separable weight tables: ay[k][py][bi] = (1/gh) sum_{iy in bin bi} wy(py; y_iy), likewise ax (1/gw).
 // (count = max(gh*gw,1) = gh*gw whenever any sample exists.)  Also the footprint box fp[k] = (ylo,yhi,xlo,xhi)
 // inclusive, empty when ylo > yhi.
@@ -393,6 +544,14 @@ static int roi_align_forward_impl(const void* x, const float* rois, void* y, voi
   if (grid > 0x7fffffffL) return CDDMSL_ERR_ARG;
   int threads = cch >= 256 ? 256 : ((cch + 63) / 64) * 64;
   hipStream_t st = (hipStream_t)stream;
+  // throughput path: one output (the crops, or only their 2x2-pooled map), bf16, every channel chunk in one block, tables that fit
+  const char* rows_env = getenv("CDDMSL_ROI_ROWS");            // "0": the tap-by-tap kernel for everything (A/B switch, read per launch)
+  const bool rows_off = rows_env && rows_env[0] == '0';
+  if (dtype == 0 && !y8 && !dbg_grid && ((y != nullptr) != (y_pooled != nullptr)) && cch <= 256 && !rows_off) {
+    if (y) k_roi_align_fwd_rows<1><<<dim3((unsigned)((long)K * ph)), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned, esc, ebi, relu);
+    else k_roi_align_fwd_rows<2><<<dim3((unsigned)((long)K * (ph / 2))), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y_pooled, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned, esc, ebi, relu);
+    return launch_status();
+  }
 #define CDDMSL_RAF(TT, RPP) k_roi_align_fwd<TT, RPP><<<dim3((unsigned)grid), dim3(threads), 0, st>>>((const char*)x, rois, (char*)y, (char*)y_pooled, dbg_grid, N, H, W, cch, ph, pw, spatial_scale, sampling_ratio, aligned, esc, ebi, relu, (char*)y8, q8, (unsigned*)amax8)
   if (dtype == 0) { if (y_pooled) CDDMSL_RAF(__bf16, 2); else CDDMSL_RAF(__bf16, 1); }
   else { if (y_pooled) CDDMSL_RAF(float, 2); else CDDMSL_RAF(float, 1); }

@@ -155,8 +155,11 @@ def test_roi_align_pooled_byproduct_is_avgpool_of_the_result(dtype):
     for sr in (0, 2):
         y = hip.roi_align_forward(x, rois, 14, 14, 1.0 / 16, sr, True)
         y2, yp = hip.roi_align_forward(x, rois, 14, 14, 1.0 / 16, sr, True, with_pooled=True)
-        assert torch.equal(y, y2)
-        assert torch.equal(yp, hip.avgpool2_fwd(y))
+        if dtype == torch.float32:
+            assert torch.equal(y, y2)
+        else:    # crops alone come from the row-sliding bf16 kernel (same sums, another order): one rounding apart at most
+            assert float((y.float() - y2.float()).abs().max()) <= 2.0 ** -7 * float(y2.float().abs().max())
+        assert torch.equal(yp, hip.avgpool2_fwd(y2))
 
 
 def test_frozen_mlp_node_matches_torch():
@@ -608,7 +611,10 @@ def test_roi_align_affine_and_pooled_entry_points(dtype, tol):
     ref = torch.relu(plain.float() * sc + bs)
     assert float((y.float() - ref).abs().max()) <= tol * float(ref.abs().max())
     yp = hip.roi_align_forward_affine(x, rois, 14, 14, 1 / 16, 0, True, pooled_only=True)
-    assert torch.equal(yp, pooled)
+    if dtype == torch.float32:
+        assert torch.equal(yp, pooled)
+    else:        # the bf16 pooled-only output averages the four UNROUNDED bins (k_roi_align_fwd_rows); `pooled` the four rounded ones
+        assert float((yp.float() - pooled.float()).abs().max()) <= 2.0 ** -7 * float(pooled.float().abs().max())
     dy = _rand((K, 7, 7, C), 43).to(dtype).cuda()
     want = hip.roi_align_backward(hip.avgpool2_bwd(dy, (K, 14, 14, C)), rois, start, (N, H, W, C), 1 / 16, 0, True)
     got = hip.roi_align_backward(dy, rois, start, (N, H, W, C), 1 / 16, 0, True, pooled=True)
@@ -712,3 +718,44 @@ def test_last_token_attention_fwd_bwd(n, t, H, dh):
     assert o.dtype == torch.bfloat16 and (o.float() - ref).abs().max() <= 1e-2 * ref.abs().max()
     assert (q.grad.float() - qf.grad).abs().max() <= 1.5e-2 * qf.grad.abs().max()
     assert (kv.grad.float() - kvf.grad).abs().max() <= 1.5e-2 * kvf.grad.abs().max()
+
+
+@pytest.mark.parametrize("sr", [0, 2])
+def test_roi_align_row_sliding_kernel_equals_the_tap_kernel(sr, monkeypatch):
+    """k_roi_align_fwd_rows (bf16 throughput forward: each feature pixel of a bin row loaded once, separable weights, sliding
+    window) against k_roi_align_fwd (tap by tap, CDDMSL_ROI_ROWS=0) and against the f32 kernel on the same bf16 input: small and
+    large RoIs, RoIs hanging over every image border, an empty box, a RoI outside the image, one whose sampling grid exceeds the
+    kernel's tables (in-kernel fallback), 64 and 256 channel chunks per row, crops / affine + ReLU / pooled-only outputs."""
+    from cddmsl_amd import hip
+    g = torch.Generator().manual_seed(23)
+    N, H, W = 2, 40, 67
+    for C in (512, 2048):
+        x = torch.randn(N, H, W, C, generator=g).bfloat16().cuda()
+        K = 48
+        b = torch.rand(K, 4, generator=g)
+        x0, y0 = b[:, 0] * W * 16 - 60, b[:, 1] * H * 16 - 60
+        rois = torch.stack([torch.randint(0, N, (K,), generator=g).float(), x0, y0, x0 + 6 + b[:, 2] ** 2 * 600, y0 + 6 + b[:, 3] ** 2 * 500], dim=1)
+        rois[3, 3:] = rois[3, 1:3]                                               # empty box
+        rois[4, 1:] = torch.tensor([-500.0, -400.0, -300.0, -250.0])             # entirely outside
+        rois[5, 1:] = torch.tensor([-4000.0, -3000.0, 6000.0, 5000.0])           # 625 x 500 feature pixels: grid beyond the tables
+        rois[6, 1:] = torch.tensor([0.0, 0.0, W * 16.0, H * 16.0])               # the whole image
+        rois = rois[rois[:, 0].argsort(stable=True)].contiguous().cuda()
+        sc, bs = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+        xf = x.float()
+        ref_f32 = hip.roi_align_forward(xf, rois, 14, 14, 1 / 16, sr, True)
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("CDDMSL_ROI_ROWS", mode)
+            got[mode] = (hip.roi_align_forward(x, rois, 14, 14, 1 / 16, sr, True),
+                         hip.roi_align_forward_affine(x, rois, 14, 14, 1 / 16, sr, True, sc, bs, relu=True),
+                         hip.roi_align_forward_affine(x, rois, 14, 14, 1 / 16, sr, True, pooled_only=True))
+        ulp = 2.0 ** -7
+        mx = float(ref_f32.abs().max())
+        assert float((got["1"][0].float() - ref_f32).abs().max()) <= ulp * mx                      # one bf16 rounding of the exact value
+        ref_aff = torch.relu(ref_f32 * sc + bs)
+        assert float((got["1"][1].float() - ref_aff).abs().max()) <= ulp * float(ref_aff.abs().max())
+        ref_pool = ref_f32.view(K, 7, 2, 7, 2, C).mean(dim=(2, 4))
+        assert float((got["1"][2].float() - ref_pool).abs().max()) <= ulp * mx
+        for a, o in zip(got["1"], got["0"]):
+            assert a.shape == o.shape and float((a.float() - o.float()).abs().max()) <= 2 * ulp * mx
+        assert bool((got["1"][0][3] == 0).all()) and bool((got["1"][0][4] == 0).all())              # empty / outside boxes pool to zero
