@@ -349,9 +349,45 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(const char* x, const
   for (int q = 0; q < 8; ++q) { R0[q] = R1[q] = acc[q] = 0.f; }
   int cur = first;
   const bool any = inb && nrow > 0 && first >= 0;
-  if (any) { rload(cur, R0); rload(min(cur + 1, W - 1), R1); }
+  // the column BEHIND the window is requested one slide ahead (raw rows in registers, up to PF merged rows): its latency passes
+  // under the bins in between instead of stalling the slide that needs it
+  constexpr int PF = 4;
+  const bool ahead = nrow <= PF;
+  int pyr[PF]; float wyr[PF];
+#pragma unroll
+  for (int e = 0; e < PF; ++e) {
+    pyr[e] = __builtin_amdgcn_readfirstlane(s_py[e < nrow ? e : 0]);
+    wyr[e] = e < nrow ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_wy[e]))) : 0.f;
+  }
+  u32x4 raw[PF];
+  auto issue = [&](int px) {
+#pragma unroll
+    for (int e = 0; e < PF; ++e) if (e < nrow) raw[e] = xb[((long)pyr[e] * W + px) * cch];
+  };
+  auto finish = [&](float* R) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) R[q] = 0.f;
+#pragma unroll
+    for (int e = 0; e < PF; ++e) if (e < nrow) {
+      float v[8];
+      Vec<__bf16>::unpack(raw[e], v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) R[q] = __builtin_fmaf(wyr[e], v[q], R[q]);
+    }
+  };
+  if (any) {
+    rload(cur, R0); rload(min(cur + 1, W - 1), R1);
+    if (ahead) issue(min(cur + 2, W - 1));
+  }
   const int spo = RP * g.gw;                                   // x samples per output
   u32x4* yo = (u32x4*)y + ((long)k * nrb + i0 / RP) * opw * cch + c;
+  if (nx == 0) {                                               // an empty box has a 0 x 0 sampling grid: every bin pools to zero
+    float o[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { o[q] = 0.f; if (esc) { o[q] = bq[q]; if (relu) o[q] = fmaxf(o[q], 0.f); } }
+    for (int jo = 0; jo < opw; ++jo) yo[(long)jo * cch] = Vec<__bf16>::pack(o);
+    return;
+  }
   int left = spo, j = 0;
   for (int s = 0; s < nx; ++s) {
     const int xl = __builtin_amdgcn_readfirstlane(s_xl[s]);
@@ -360,7 +396,8 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(const char* x, const
         ++cur;
 #pragma unroll
         for (int q = 0; q < 8; ++q) R0[q] = R1[q];
-        rload(min(cur + 1, W - 1), R1);
+        if (ahead) { finish(R1); issue(min(cur + 2, W - 1)); }
+        else rload(min(cur + 1, W - 1), R1);
       }
       const float wl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_xwl[s])));
       const float wh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_xwh[s])));
