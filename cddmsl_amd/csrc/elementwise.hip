@@ -231,19 +231,26 @@ __global__ void k_meanpool_bwd(const float* dy, char* dx, long K, int P, int C) 
 // ---------------------------------------------------------------- attention-pool tokens
 // x [K][P][C] (P = 49 pixels) -> tok [K][TP][C] (TP >= P+1 token rows per region in memory; rows P+1.. are zero):
 // tok0 = mean_p x + pos[0], tok_{i+1} = x_i + pos[i+1]
+// mbits (nullable, P <= 64): one 64-bit word per region and column, bit p = (x[k][p][col] > 0) -- the ReLU mask of the pooled map
+// in the form the backward's fused epilogue reads (cddmsl_attnpool_dx): 8 bytes per column instead of P elements
 template <typename T>
-__global__ void k_attn_tokens_fwd(const char* x, const float* pos, char* tok, int K, int P, int TP, int cch) {
+__global__ void k_attn_tokens_fwd(const char* x, const float* pos, char* tok, unsigned long long* mbits, int K, int P, int TP, int cch) {
   long total = (long)K * cch;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     int c = i % cch; long k = i / cch;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8], o[8];
+    unsigned long long mb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int VEC = Elt<T>::VEC;
     for (int p = 0; p < P; ++p) {
       Elt<T>::unpack(((const u32x4*)x)[(k * P + p) * cch + c], v);
       const float* pe = pos + (long)(p + 1) * cch * VEC + c * VEC;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) { s[j] += v[j]; o[j] = v[j] + pe[j]; }
+      for (int j = 0; j < VEC; ++j) { s[j] += v[j]; o[j] = v[j] + pe[j]; mb[j] |= (unsigned long long)(v[j] > 0.f) << p; }
       ((u32x4*)tok)[(k * TP + p + 1) * cch + c] = Elt<T>::pack(o);
+    }
+    if (mbits) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) mbits[(k * cch + c) * VEC + j] = mb[j];
     }
     const float* pe = pos + c * VEC;
 #pragma unroll
@@ -634,7 +641,19 @@ extern "C" int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok
   int cch = C * es / 16;
   long total = (long)K * cch;
   if (total == 0) return CDDMSL_OK;
-  DISPATCH(dtype, k_attn_tokens_fwd, <<<dim3(gsz(total, 64)), dim3(64), 0, (hipStream_t)stream>>>((const char*)x, pos, (char*)tok, K, P, TP, cch));
+  DISPATCH(dtype, k_attn_tokens_fwd, <<<dim3(gsz(total, 64)), dim3(64), 0, (hipStream_t)stream>>>((const char*)x, pos, (char*)tok, nullptr, K, P, TP, cch));
+  return launch_status();
+}
+
+// the same, also writing the pooled map's sign bits (one 64-bit word per region and column, bit p = x[k][p][col] > 0; P <= 64)
+extern "C" int cddmsl_attn_tokens_fwd_mask(const void* x, const float* pos, void* tok, unsigned long long* mbits, int K, int P, int TP, int C,
+                                           int dtype, void* stream) {
+  int es = dtype == 0 ? 2 : 4;
+  if ((C * es) % 16 || P <= 0 || P > 64 || TP < P + 1 || K < 0 || !mbits) return CDDMSL_ERR_ARG;
+  int cch = C * es / 16;
+  long total = (long)K * cch;
+  if (total == 0) return CDDMSL_OK;
+  DISPATCH(dtype, k_attn_tokens_fwd, <<<dim3(gsz(total, 64)), dim3(64), 0, (hipStream_t)stream>>>((const char*)x, pos, (char*)tok, mbits, K, P, TP, cch));
   return launch_status();
 }
 

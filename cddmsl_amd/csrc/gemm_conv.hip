@@ -710,6 +710,11 @@ struct WgradArgs {
   int ldo;            // output row stride in elements (default K)
   int direct;         // 0: f32 atomicAdd (split reductions); 1: plain f32 store; 2: plain T store (single split only)
   long bx, bd, bo;    // batch (gridDim.y) byte strides of x, dy, out
+  // k_gemm_tn_small MODE 3 (cddmsl_attnpool_dx): per-batch row vector added to every output row, bit masks of the rows to keep,
+  // f32 accumulator of the unmasked rows
+  const float* g0 = nullptr;
+  const unsigned long long* mbits = nullptr;
+  float* gpos = nullptr;
   float* ws = nullptr;  // split reductions through a workspace: block (split, tile) stores its accumulators, in fragment order, at
                         // ws[(split * ntiles + tile) * tile_floats ...]; k_wgrad_reduce sums the splits into dw (see cddmsl_set_workspace)
 #ifdef CDDMSL_TILE_STAMPS
@@ -1203,9 +1208,27 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_stream(WgradArgs p, int nbat
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int NG, int MODE>
+// MODE 3 (the attention pool's input gradient, cddmsl_attnpool_dx; P = pixels per region): the product's rows are the token
+// gradients  dtok[t] = sum_h (p[h][t] dZ[h] + dS[h][t] U[h]),  t = 0 the mean token.  Instead of storing them (and reading them back in
+// a second kernel) the epilogue writes the map's gradient directly,  dx[t-1] = dtok[t] + (dtok[0] + g0) / P  for t = 1..P, zeroed where
+// bit t-1 of the column's mask word is clear (the pooled map is a ReLU output: its sign bits, one 64-bit word per region and column,
+// written by cddmsl_attn_tokens_fwd), and keeps the UNMASKED column sums of dtok[t] (t = 0 includes g0: the query path's gradient of
+// the mean token) in registers over the block's run of regions: the positional embedding's gradient, one atomic per element at the end.
+// Two more loads per wave and item (g0, mask word), issued in front of the item's stage so that the counted waits stay exact.
+template <int NG, int P>
+constexpr int tn_small_stores3() {
+  int n = 0;
+  for (int a = 0; a < (NG + 3) / 4; ++a)
+    for (int g = 0; g < 16; ++g) {
+      if (a * 4 + (g >> 2) >= NG) continue;
+      const int n0 = a * 32 + (g & 3) + 8 * (g >> 2);
+      if ((n0 >= 1 && n0 <= P) || (n0 + 4 >= 1 && n0 + 4 <= P)) ++n;
+    }
+  return n;
+}
+template <int NG, int MODE, int P = 0>
 __global__ __launch_bounds__(256, 2) void k_gemm_tn_small(WgradArgs p, int nbatch, int bpb) {
-  constexpr int NTN = (NG + 3) / 4, NSTORE = 4 * NG;
+  constexpr int NTN = (NG + 3) / 4, NSTORE = MODE == 3 ? tn_small_stores3<NG, P>() : 4 * NG, NML = MODE == 3 ? 2 : 0;
   constexpr int STAGE = 8192 + 16384, NST = 3;
   __shared__ __attribute__((aligned(16))) char lds[NST * STAGE];
   const int t = threadIdx.x, lane = t & 63;
@@ -1256,16 +1279,38 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_small(WgradArgs p, int nbatc
     xoff[0] = 8192 + o.o0; xoff[1] = 8192 + o.o1;
   }
   const int r = lane & 31, h = lane >> 5;
+  f32x16 gacc[MODE == 3 ? NTN : 1];
+  if (MODE == 3) {
+#pragma unroll
+    for (int a = 0; a < NTN; ++a)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) gacc[a][g] = 0.f;
+  }
   if (nit > 0) stage(0);
   if (nit > 1) stage(1);
-  for (int it = 0; it < nit; ++it) {
+  // One item.  KIND (compile time): 2 = two more items follow (stage it+2 is issued here), 1 = one more follows, 0 = the last.
+  // The three kinds run as three pieces of straight-line code (loop, tail, tail), so that MODE 3's two per-item loads -- plain
+  // loads the compiler waits for by itself, counting the DMA instructions issued behind them -- are not merged across paths with
+  // different numbers of younger operations (a merged path waits for vmcnt(0), i.e. for the DMAs just issued).
+  auto item = [&](int it, auto KIND) {
+    constexpr int kind = decltype(KIND)::value;
     const int slot = it % NST;
-    // younger than stage `it`: stage it+1 (6 DMAs), the stores of item it-1, stage it+2 (6 DMAs)
-    if (it + 2 < nit) {
+    float g0v = 0.f;
+    u32x2 mbv = {~0u, ~0u};
+    if (MODE == 3) {                                 // this item's row vector and mask word: requested BEFORE stage it+2
+      // (inline asm + a counted wait below: hipcc's own wait for a plain load issued in front of LDS-DMA instructions is vmcnt(0))
+      const long ci = (long)(b0 + it) * p.K + k0 + wvu * 32 + r;
+      const char* gp = (const char*)(p.g0 + ci);
+      const char* mp = (const char*)(p.mbits + ci);
+      asm volatile("global_load_dword %0, %1, off" : "=v"(g0v) : "v"(gp) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(mbv) : "v"(mp) : "memory");
+    }
+    // younger than stage `it`: stage it+1 (6 DMAs), the stores of item it-1, [the two loads above,] stage it+2 (6 DMAs)
+    if (kind == 2) {
       stage((it + 2) % NST);
-      if (it) wait_vm<12 + NSTORE>(); else wait_vm<12>();
-    } else if (it + 1 < nit) {
-      if (it) wait_vm<6 + NSTORE>(); else wait_vm<6>();
+      if (it) wait_vm<12 + NML + NSTORE>(); else wait_vm<12 + NML>();
+    } else if (kind == 1) {
+      if (it) wait_vm<6 + NML + NSTORE>(); else wait_vm<6 + NML>();
     } else {
       wait_vm<0>();
     }
@@ -1297,6 +1342,39 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_small(WgradArgs p, int nbatc
     __builtin_amdgcn_s_barrier();                    // every wave is done with this slot before the next iteration restages it
     char* outp = (char*)p.dw + (long)(b0 + it) * p.bo;
     const int k = k0 + wvu * 32 + r;
+    if (MODE == 3) {
+      // the two loads are older than stage it+2's six DMAs (kind 2); the registers are named by the wait so that no use precedes it
+      if (kind == 2) asm volatile("s_waitcnt vmcnt(6)" : "+v"(g0v), "+v"(mbv) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(g0v), "+v"(mbv) :: "memory");
+      // row 0 (the mean token) of this column sits in lane r (< 32), register 0: v_permlane32_swap hands the lower half-wave's values
+      // to the upper one (not a DS instruction: a compiler-visible LDS operation here would make hipcc wait for the LDS-DMAs in flight)
+      const unsigned a00 = __builtin_bit_cast(unsigned, acc[0][0]);
+      const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(a00, a00, false, false)[0]) + g0v;
+      const float base = t0 * (1.0f / (float)(P > 0 ? P : 1));
+      const unsigned mlo = mbv[0], mhi = mbv[1];
+#pragma unroll
+      for (int a = 0; a < NTN; ++a)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int n0 = a * 32 + (g & 3) + 8 * (g >> 2);
+          const bool exists = a * 4 + (g >> 2) < NG;
+          const bool lo_ok = n0 >= 1 && n0 <= P, hi_ok = n0 + 4 >= 1 && n0 + 4 <= P;       // (compile-time after unrolling)
+          if (exists) {
+            const int n = n0 + 4 * h;
+            const float v = acc[a][g];
+            gacc[a][g] += (n == 0) ? t0 : v;
+            if (lo_ok || hi_ok) {
+              if (h ? hi_ok : lo_ok) {
+                const unsigned word = (n - 1) < 32 ? mlo : mhi;
+                const bool keep = (word >> ((n - 1) & 31)) & 1u;
+                Mma<__bf16>::store(outp + ((long)(n - 1) * p.ldo + k) * 2, keep ? v + base : 0.f);
+              }
+            }
+          }
+          acc[a][g] = 0.f;
+        }
+      return;
+    }
 #pragma unroll
     for (int a = 0; a < NTN; ++a)
 #pragma unroll
@@ -1310,6 +1388,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_small(WgradArgs p, int nbatc
           else Mma<__bf16>::store(outp + o * 2, v);
         }
         acc[a][g] = 0.f;
+      }
+  };
+  {
+    int it = 0;
+    for (; it + 2 < nit; ++it) item(it, std::integral_constant<int, 2>{});
+    if (it + 1 < nit) { item(it, std::integral_constant<int, 1>{}); ++it; }
+    if (it < nit) item(it, std::integral_constant<int, 0>{});
+  }
+  if (MODE == 3 && p.gpos) {
+    const int k = k0 + wvu * 32 + r;
+#pragma unroll
+    for (int a = 0; a < NTN; ++a)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int n = a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (a * 4 + (g >> 2) < NG && n <= P) atomicAdd(p.gpos + (long)n * p.K + k, gacc[a][g]);
       }
   }
 }
@@ -3075,6 +3169,32 @@ extern "C" int cddmsl_gemm_tn_batched(const void* a, const void* b, void* out, i
   if (g_plan_only) return CDDMSL_OK;
   if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad_dma<__bf16>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(k_conv_wgrad_dma<float>, dim3((unsigned)grid, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+// dx [K][P][C] (bf16) and gpos [P+1][C] (f32, accumulated; nullable) of the CLIP attention pool from  pds [K][2H][TP] = [p ; ds]
+// and  zu [K][2H][C] = [dZ ; U]  (cddmsl_amd/layers.py AttnPoolFn.backward; clip_backbone.py:83-107):  one batched TN product whose
+// epilogue finishes the token gradients (see k_gemm_tn_small MODE 3).  g0 [K][C] f32 = the query path's gradient of the mean token;
+// mbits [K][C] = sign bits of the pooled map per column (bit t = pixel t kept), all ones when the map is not a ReLU output.
+extern "C" int cddmsl_attnpool_dx(const void* pds, const void* zu, const float* g0, const unsigned long long* mbits, void* dx, float* gpos,
+                                  int K, int H2, int P, int TP, int C, int dtype, void* stream) {
+  if (dtype != 0 || K < 0 || P != 49 || TP != 56 || H2 <= 0 || H2 > 64 || (H2 & 7) || C <= 0 || (C & 127) || !g0 || !mbits || !dx) return CDDMSL_ERR_ARG;
+  if (K == 0) return CDDMSL_OK;
+  if (K > 65535 * 8) return CDDMSL_ERR_ARG;
+  WgradArgs p;
+  p.x = (const char*)zu; p.dy = (const char*)pds; p.dw = (float*)dx; p.scale = nullptr;
+  p.Nimg = 1; p.Hi = 1; p.Wi = H2; p.Cin = C; p.Ho = 1; p.Wo = H2; p.Cout = TP; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+  p.ldd = TP; p.pool = 0; p.M = H2; p.cpp = C * 2 / 16; p.Kc = p.cpp; p.K = C; p.ncc = TP * 2 / 16;
+  p.dWo = make_fastdiv((unsigned)H2); p.dHo = make_fastdiv(1u);
+  p.xrs = C * 2 / 16; p.ldo = C; p.direct = 3;
+  p.bx = (long)H2 * C * 2; p.bd = (long)H2 * TP * 2; p.bo = (long)P * C * 2;
+  p.g0 = g0; p.mbits = mbits; p.gpos = gpos;
+  const long kt = C / 128;
+  long bpb = (kt * K + 4095) / 4096;
+  if (bpb < 8) bpb = 8;
+  if (bpb > K) bpb = K;
+  const unsigned gy = (unsigned)((K + bpb - 1) / bpb);
+  hipLaunchKernelGGL((k_gemm_tn_small<7, 3, 49>), dim3((unsigned)kt, gy), dim3(256), 0, (hipStream_t)stream, p, K, (int)bpb);
   return launch_status();
 }
 

@@ -72,6 +72,8 @@ def _L():
         L.cddmsl_focal_ce_bwd.argtypes = [vp] * 5 + [c_long, ci, cf, ci, cf, vp]
         L.cddmsl_attn_small_fwd.argtypes = [vp] * 4 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_attn_small_bwd.argtypes = [vp] * 7 + [ci] * 8 + [cf, ci, vp]
+        L.cddmsl_attn_tokens_fwd_mask.argtypes = [vp] * 4 + [ci] * 5 + [vp]
+        L.cddmsl_attnpool_dx.argtypes = [vp] * 6 + [ci] * 6 + [vp]
         L.cddmsl_attn_last_fwd.argtypes = [vp] * 4 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_attn_last_bwd.argtypes = [vp] * 6 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_contrastive_fwd.argtypes = [vp] * 4 + [ci, ci, vp]
@@ -445,6 +447,38 @@ def attn_tokens_fwd(x, pos, tp=None):
     tok = torch.empty((K, tp, C), device=x.device, dtype=x.dtype)
     check(_L().cddmsl_attn_tokens_fwd(ptr(x), ptr(pos), ptr(tok), K, P, tp, C, _dt(x), stream_ptr()), "cddmsl_attn_tokens_fwd")
     return tok
+
+
+@_timed("attn_tokens_fwd")
+def attn_tokens_fwd_mask(x, pos, tp=None):
+    """the same, plus mbits [K,C] int64: bit p of a column's word = (x[k,p,col] > 0) -- the pooled map's ReLU mask for ``attnpool_dx``"""
+    require_cuda(x, pos)
+    K, P, C = x.shape
+    tp = tp or P + 1
+    assert pos.dtype == torch.float32 and tuple(pos.shape) == (P + 1, C) and x.is_contiguous() and pos.is_contiguous() and P <= 64
+    tok = torch.empty((K, tp, C), device=x.device, dtype=x.dtype)
+    mbits = torch.empty((K, C), device=x.device, dtype=torch.int64)
+    check(_L().cddmsl_attn_tokens_fwd_mask(ptr(x), ptr(pos), ptr(tok), ptr(mbits), K, P, tp, C, _dt(x), stream_ptr()), "cddmsl_attn_tokens_fwd_mask")
+    return tok, mbits
+
+
+def attnpool_dx_ok(K, H, P, TP, C, dtype):
+    return dtype == torch.bfloat16 and P == 49 and TP == 56 and 2 * H <= 64 and (2 * H) % 8 == 0 and C % 128 == 0 and 0 < K <= 65535 * 8
+
+
+@_timed("attnpool_dx")
+def attnpool_dx(pds, zu, g0, mbits, P, gpos=None):
+    """pds [K,2H,TP] = [p ; ds], zu [K,2H,C] = [dZ ; U] (bf16), g0 [K,C] f32, mbits [K,C] int64 -> dx [K,P,C] bf16 (masked),
+    gpos [P+1,C] f32 accumulated when given: the token-gradient product with its epilogue fused (cddmsl_attnpool_dx)"""
+    require_cuda(pds, zu, g0, mbits)
+    K, H2, TP = pds.shape
+    C = zu.shape[2]
+    assert pds.dtype == zu.dtype == torch.bfloat16 and g0.dtype == torch.float32 and mbits.dtype == torch.int64
+    assert pds.is_contiguous() and zu.is_contiguous() and g0.is_contiguous() and mbits.is_contiguous() and tuple(zu.shape) == (K, H2, C)
+    assert tuple(g0.shape) == (K, C) and tuple(mbits.shape) == (K, C) and (gpos is None or (gpos.dtype == torch.float32 and tuple(gpos.shape) == (P + 1, C) and gpos.is_contiguous()))
+    dx = torch.empty((K, P, C), device=pds.device, dtype=pds.dtype)
+    check(_L().cddmsl_attnpool_dx(ptr(pds), ptr(zu), ptr(g0), ptr(mbits), ptr(dx), ptr(gpos), K, H2, P, TP, C, 0, stream_ptr()), "cddmsl_attnpool_dx")
+    return dx
 
 
 @_timed("attn_tokens_bwd")

@@ -9,6 +9,7 @@ Conventions
   * weight gradients are accumulated by the wgrad kernels straight into ``param.grad`` (f32, same
     memory layout as the parameter) -- the Functions return ``None`` for parameter inputs.
 """
+import os
 import weakref
 
 import torch
@@ -800,7 +801,13 @@ class AttnPoolFn(torch.autograd.Function):
         D = C // H
         assert ap.pos.shape[0] == P + 1 <= TP, "attention pool needs a 7x7 map (clip_backbone.py:86)"
         dev = x.device
-        tok = hip.attn_tokens_fwd(x.view(K, P, C), ap.pos.detach(), TP)                      # [K,TP,C]
+        # the fused input-gradient epilogue (cddmsl_attnpool_dx) reads the pooled map's ReLU mask as one 64-bit word per column
+        fused_dx = hip.attnpool_dx_ok(K, H, P, TP, C, T) and bool(ctx.needs_input_grad[0]) and os.environ.get("CDDMSL_ATTNPOOL_DX", "1") != "0"
+        mbits = None
+        if fused_dx and premask_input_grad:
+            tok, mbits = hip.attn_tokens_fwd_mask(x.view(K, P, C), ap.pos.detach(), TP)       # [K,TP,C], [K,C]
+        else:
+            tok = hip.attn_tokens_fwd(x.view(K, P, C), ap.pos.detach(), TP)                  # [K,TP,C]
         wq, _ = ap.pq.get(T, False)
         wk, wkT = ap.pk.get(T, True)                                                          # [C,1,1,C]: rows = hd ; rows = c
         wv, wvT = ap.pv.get(T, True)
@@ -823,14 +830,15 @@ class AttnPoolFn(torch.autograd.Function):
         o = o + ap.v_b.detach().to(T)
         out = hip.conv_fwd(o.view(1, 1, K, C), wc, None, ap.c_b.detach(), out_f32=True).view(K, -1)
         ctx.ap = ap
-        ctx.save_for_backward(tok, q0, zu, p, z, o)
+        ctx.fused_dx = fused_dx
+        ctx.save_for_backward(tok, q0, zu, p, z, o, mbits)
         ctx.shape = (K, h, w, C)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ap = ctx.ap
-        tok, q0, zu, p, z, o = ctx.saved_tensors
+        tok, q0, zu, p, z, o, mbits = ctx.saved_tensors
         K, h, w, C = ctx.shape
         P, TP, H = h * w, AttnPoolFn.TP, ap.heads
         D = C // H
@@ -859,9 +867,6 @@ class AttnPoolFn(torch.autograd.Function):
         # dU[k] (H x C) = dS[k] (H x TP) . tok[k]
         du = torch.empty((K, H, C), device=dev, dtype=T)
         hip.gemm_tn_batched(dsT, tok, du, TP, H, C, H, C, C, K, TP * H, TP * C, H * C)
-        # dtok[k] (TP x C) = [P[k]; dS[k]]^T (TP x 2H) . [dZ[k]; U[k]] (2H x C)     (reduction over the 2H stacked rows)
-        dtok = torch.empty((K, TP, C), device=dev, dtype=T)
-        hip.gemm_tn_batched(pds, zu, dtok, 2 * H, TP, C, TP, C, C, K, 2 * H * TP, 2 * H * C, TP * C)
         # dq0[k, hD:(h+1)D] = dU[k,h,:] @ Wk[hD:(h+1)D, :]^T
         dq0 = torch.empty((K, C), device=dev, dtype=T)
         hip.gemm_nt_batched(du, wk, dq0, K, D, C, H * C, C, C, H, C, D * C, D)
@@ -872,10 +877,22 @@ class AttnPoolFn(torch.autograd.Function):
             hip.conv_wgrad(tok.view(K, 1, TP, C), dq0.view(K, 1, 1, C), _ohwi(ap.q_w).shape, stride=TP, out=_ohwi(_grad_buf(ap.q_w)))
             hip.colsum(dq0, out=_grad_buf(ap.q_b))
         _, wqd = ap.pq.get(T, True)
-        dtok[:, 0, :] += hip.conv_fwd(dq0.view(1, 1, K, C), wqd).view(K, C)
-        # one pass over dtok: the positional embedding's gradient (column sums per token row) and the map's gradient
         gpos = _grad_buf(ap.pos) if train else None
         want_dx = ctx.needs_input_grad[0]
+        if ctx.fused_dx and want_dx:
+            # dtok[k] = [P[k]; dS[k]]^T . [dZ[k]; U[k]] is never stored: the product's epilogue adds the mean token's share
+            # (its own row + the query path's g0 = Wq^T dq0, over the 49 pixels), applies the map's ReLU mask and keeps the
+            # positional embedding's gradient (the unmasked column sums) -- one pass instead of product + read-back pass
+            g0 = hip.conv_fwd(dq0.view(1, 1, K, C), wqd, out_f32=True).view(K, C)
+            if mbits is None:
+                mbits = torch.full((K, C), -1, device=dev, dtype=torch.int64)
+            dx = hip.attnpool_dx(pds, zu, g0, mbits, P, gpos)
+            return dx.view(K, h, w, C), None, None, None
+        # dtok[k] (TP x C) = [P[k]; dS[k]]^T (TP x 2H) . [dZ[k]; U[k]] (2H x C)     (reduction over the 2H stacked rows)
+        dtok = torch.empty((K, TP, C), device=dev, dtype=T)
+        hip.gemm_tn_batched(pds, zu, dtok, 2 * H, TP, C, TP, C, C, K, 2 * H * TP, 2 * H * C, TP * C)
+        dtok[:, 0, :] += hip.conv_fwd(dq0.view(1, 1, K, C), wqd).view(K, C)
+        # one pass over dtok: the positional embedding's gradient (column sums per token row) and the map's gradient
         dx = None
         if want_dx or train:
             dx = hip.attn_tokens_bwd(dtok, P, ctx.relu_src if want_dx else None, gpos, want_dx)

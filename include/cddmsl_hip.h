@@ -164,6 +164,16 @@ int cddmsl_iou_match_batched(const float* gt, const int* gt_off, const float* pr
 /* ---- CLIP attention pool (modeling/backbone/clip_backbone.py:83-107): token build/backward; the query-0 attention itself is
  * reassociated into the batched GEMMs above (cddmsl_amd/layers.py::AttnPoolFn) ------------------------------------- */
 int cddmsl_attn_tokens_fwd(const void* x, const float* pos, void* tok, int K, int P, int TP, int C, int dtype, void* stream);
+/* the same, also writing mbits [K][C] (64-bit words, P <= 64): bit p = (x[k][p][col] > 0), the ReLU mask of the pooled map in the
+ * form cddmsl_attnpool_dx reads */
+int cddmsl_attn_tokens_fwd_mask(const void* x, const float* pos, void* tok, unsigned long long* mbits, int K, int P, int TP, int C,
+                                int dtype, void* stream);
+/* The pool's input gradient in ONE pass (bf16, P = 49, TP = 56, C % 128 == 0): the batched product  dtok[k] = [p ; ds][k]^T . [dZ ; U][k]
+ * (pds [K][H2][TP], zu [K][H2][C], H2 = 2 x heads <= 64) with the epilogue  dx[k][t-1] = dtok[t] + (dtok[0] + g0[k]) / P  for t = 1..P,
+ * zeroed where bit t-1 of mbits[k][col] is clear, and  gpos[t] += sum_k dtok[k][t]  (t = 0: + g0[k]; f32 atomics, nullable) --
+ * replaces the stored token gradients + cddmsl_attn_tokens_bwd.  g0 [K][C] f32: the query path's gradient of the mean token. */
+int cddmsl_attnpool_dx(const void* pds, const void* zu, const float* g0, const unsigned long long* mbits, void* dx, float* gpos, int K,
+                       int H2, int P, int TP, int C, int dtype, void* stream);
 /* relu_mask (nullable, [K][P][C]): dx is zeroed where it is <= 0 -- the pooled map when it is a ReLU output (layer4 -> attnpool,
  * clip_roi_heads.py:160-165), so the stage's ReLU backward needs no pass of its own.  gpos (nullable, f32 [P+1][C]) accumulates
  * (atomics) the positional embedding's gradient sum_k dtok[k][t][:] in the same pass; dx may be NULL when only gpos is wanted */

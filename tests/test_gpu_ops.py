@@ -763,3 +763,52 @@ def test_roi_align_row_sliding_kernel_equals_the_tap_kernel(sr, monkeypatch):
         # the box outside the image pools to zero; so does the empty one under the adaptive grid (0 x 0 samples; a fixed grid samples its one point)
         zero = ((rois[:, 3] < -100) | ((rois[:, 3] == rois[:, 1]) if sr == 0 else torch.zeros_like(rois[:, 0], dtype=torch.bool))).nonzero().flatten().tolist()
         assert len(zero) == (2 if sr == 0 else 1) and all(bool((got["1"][0][i] == 0).all()) for i in zero)
+
+
+@pytest.mark.parametrize("premask", [False, True])
+def test_attention_pool_input_gradient_fused_epilogue(premask, monkeypatch):
+    """cddmsl_attnpool_dx (the token-gradient product with the map's gradient, the ReLU mask as bit words and the positional
+    embedding's gradient in its epilogue) against the stored-dtok route (CDDMSL_ATTNPOOL_DX=0: product, ``dtok[:, 0] +=``,
+    cddmsl_attn_tokens_bwd): the map's gradient, every parameter gradient of the pool, and -- the kernel alone -- against an f32
+    torch evaluation of its definition.  300 regions (run boundaries of the streaming kernel: 8-region blocks + a tail)."""
+    from cddmsl_amd import hip, layers
+    K, C, H, P, TP = 300, 2048, 32, 49, 56
+    g = torch.Generator().manual_seed(5)
+    # the kernel against its definition
+    pds = (torch.randn(K, 2 * H, TP, generator=g) * 0.3).bfloat16().cuda()
+    pds[:, :, P + 1:] = 0
+    zu = torch.randn(K, 2 * H, C, generator=g).bfloat16().cuda()
+    g0 = torch.randn(K, C, generator=g).cuda()
+    xm = torch.randn(K, P, C, generator=g).cuda()
+    bits = ((xm > 0).long() << torch.arange(P, device="cuda").view(1, P, 1)).sum(1)
+    gpos = torch.full((P + 1, C), 0.25, device="cuda")
+    dx = hip.attnpool_dx(pds, zu, g0, bits, P, gpos)
+    dtok = torch.einsum("kht,khc->ktc", pds.float(), zu.float())
+    dtok[:, 0] += g0
+    want = (dtok[:, 1:P + 1] + dtok[:, :1] / P) * (xm > 0)
+    assert float((dx.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+    wpos = 0.25 + dtok[:, :P + 1].double().sum(0)
+    assert float((gpos.double() - wpos).abs().max()) <= 1e-4 * float(wpos.abs().max())
+    # the whole pool, both routes
+    pos = (torch.randn(P + 1, C, generator=g) * 0.05).cuda().requires_grad_(True)
+    mk = lambda o, i, s: (torch.randn(o, i, generator=g) * s).cuda().requires_grad_(True)
+    ws = [mk(C, C, C ** -0.5) for _ in range(3)] + [mk(1024, C, C ** -0.5)]
+    bs = [(torch.randn(n, generator=g) * 0.1).cuda().requires_grad_(True) for n in (C, C, C, 1024)]
+    x0 = torch.relu(torch.randn(K, 7, 7, C, generator=g)).bfloat16().cuda()
+    dout = torch.randn(K, 1024, generator=g).cuda()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CDDMSL_ATTNPOOL_DX", mode)
+        for t in [pos] + ws + bs:
+            t.grad = None
+        ap = layers.AttnPoolParams(pos, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], ws[3], bs[3], H)
+        x = x0.clone().requires_grad_(True)
+        out = layers.AttnPoolFn.apply(x, ws[0], ap, premask)
+        out.backward(dout)
+        res[mode] = [x.grad.float()] + [t.grad.float().clone() for t in [pos] + ws + bs]
+    names = ["dx", "pos", "q_w", "k_w", "v_w", "c_w", "q_b", "k_b", "v_b", "c_b"]
+    for n, a, b in zip(names, res["1"], res["0"]):
+        tol = 2.0 ** -6 if n in ("dx", "pos") else 1e-3       # (dx / pos: one bf16 rounding less on the fused route; the rest is untouched)
+        assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6), n
+    if premask:
+        assert bool((res["1"][0][x0.float() <= 0] == 0).all())
