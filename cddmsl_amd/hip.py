@@ -174,8 +174,18 @@ def _dt(t):
     return DT[t.dtype]
 
 
+class OutSpec:
+    """Where a convolution puts its result when two launches' outputs have to end up adjacent (rows [0, N) and [N, 2N) of ONE
+    buffer) without a concatenation copy: the first launch (``full`` None) allocates the double buffer, writes its half and
+    records it; the second (``full`` set) writes rows [N, 2N).  Anything that does not fit leaves ``full`` / ``used`` untouched
+    and the caller falls back to ``torch.cat``."""
+
+    def __init__(self):
+        self.full, self.used = None, 0
+
+
 def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=None, stride=1, pad=0,
-             pool=False, out_f32=False, residual_pooled=False, emit8=None):
+             pool=False, out_f32=False, residual_pooled=False, emit8=None, out_spec=None):
     """x NHWC [N,H,W,Cin]; w [Cout,KH,KW,Cin] (same dtype).  Returns NHWC [N,Ho,Wo,Cout].
     y = relu?(acc*scale[n] + bias[n] + residual), zeroed where relu_mask <= 0 (ReLU backward).
     pool=True: 1x1 conv over the 2x2 average-pooled input (AvgPool2d(2) fused into the loader).
@@ -192,7 +202,14 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
         Ho, Wo = H // 2, W // 2
     else:
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    ydt = torch.float32 if out_f32 else x.dtype
+    if out_spec is not None and out_spec.full is None:
+        out_spec.full = torch.empty((2 * N, Ho, Wo, Cout), device=x.device, dtype=ydt)
+        y, out_spec.used = out_spec.full[:N], 1
+    elif out_spec is not None and out_spec.used == 1 and tuple(out_spec.full.shape) == (2 * N, Ho, Wo, Cout) and out_spec.full.dtype == ydt:
+        y, out_spec.used = out_spec.full[N:], 2
+    else:
+        y = torch.empty((N, Ho, Wo, Cout), device=x.device, dtype=ydt)
     for v in (scale, bias):
         assert v is None or (v.dtype == torch.float32 and v.numel() == Cout and v.is_contiguous())
     res_f32 = residual is not None and residual.dtype == torch.float32 and x.dtype != torch.float32

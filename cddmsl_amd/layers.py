@@ -230,7 +230,7 @@ def conv_fwd_auto(x, pw, scale=None, bias=None, fp8=False, emit8=None, **kw):
     the epilogue's per-channel scale.  ``emit8``: (scale, amax) for an e4m3 copy of the OUTPUT (``fp8_emit_for``).
     kw: residual, relu, relu_mask, pad."""
     T = x.dtype
-    if fp8 and T == torch.bfloat16 and kw.get("stride", 1) == 1 and not kw.get("out_f32", False):
+    if fp8 and T == torch.bfloat16 and kw.get("stride", 1) == 1 and not kw.get("out_f32", False) and kw.get("out_spec") is None:
         Cout = _ohwi(pw.param).shape[0]
         pad = kw.get("pad", 0)
         if _fp8_eligible(pw, x.shape, pad):
@@ -485,7 +485,7 @@ class BlockParams:
         self.pw = tuple(None if w is None else PreparedWeight(w, b[0], frozen) for w, b in zip(self.w, self.bn))
 
 
-def _block_forward(x, bp, save, px_given=None, next_pw=None):
+def _block_forward(x, bp, save, px_given=None, next_pw=None, out_spec=None):
     # (next_pw: conv1 of the block that reads this block's output -- fp8 configuration: its e4m3 copy is written here)
     """Bottleneck forward (clip_backbone.py:57-70).  AvgPool2d(stride) runs as its own HBM-bound kernel: fusing it into
     the GEMM A-loader (kernel option pool=1, kept and tested) halves the MFMA rate of this kernel structure."""
@@ -505,7 +505,7 @@ def _block_forward(x, bp, save, px_given=None, next_pw=None):
     else:
         idn = x
     out_shape = (p2.shape[0], p2.shape[1], p2.shape[2], _ohwi(bp.w[2]).shape[0])
-    out = conv_fwd_auto(p2, bp.pw[2], s3, b3, f8, emit8=fp8_emit_for(next_pw, out_shape, 0, f8), residual=idn, relu=True)
+    out = conv_fwd_auto(p2, bp.pw[2], s3, b3, f8, emit8=fp8_emit_for(next_pw, out_shape, 0, f8), residual=idn, relu=True, out_spec=out_spec)
     return out, ((o1, o2, p2 if pool else None, px if pool else None) if save else None)
 
 
@@ -556,12 +556,13 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None):
 
 class ResStageFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, anchor, blocks, out_grad_premasked=False, px0=None):
+    def forward(ctx, x, anchor, blocks, out_grad_premasked=False, px0=None, out_spec=None):
         ctx.out_grad_premasked = out_grad_premasked
         saved = [x]
         cur = x
         for bi, bp in enumerate(blocks):
-            cur, mids = _block_forward(cur, bp, True, px0 if bi == 0 else None, blocks[bi + 1].pw[0] if bi + 1 < len(blocks) else None)
+            cur, mids = _block_forward(cur, bp, True, px0 if bi == 0 else None, blocks[bi + 1].pw[0] if bi + 1 < len(blocks) else None,
+                                       out_spec if bi + 1 == len(blocks) else None)
             saved += [mids[0], mids[1], mids[2], mids[3], cur]
         ctx.blocks = blocks
         ctx.save_for_backward(*saved)
@@ -577,18 +578,40 @@ class ResStageFn(torch.autograd.Function):
         for i in range(len(blocks) - 1, -1, -1):
             x, o1, o2, p2, px = saved[5 * i: 5 * i + 5]
             gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0, prev_bp=blocks[i - 1] if i > 0 else None)
-        return gs, None, None, None, None
+        return gs, None, None, None, None, None
 
 
-def res_stage(x, blocks, frozen, out_grad_premasked=False):
-    """Runs a residual stage.  Frozen stages (FREEZE_AT) and no-grad calls keep no activations."""
+def res_stage(x, blocks, frozen, out_grad_premasked=False, out_spec=None):
+    """Runs a residual stage.  Frozen stages (FREEZE_AT) and no-grad calls keep no activations.  ``out_spec`` (hip.OutSpec): the
+    stage output is written into one half of a buffer shared with a second pass (no concatenation copy later)."""
     px0 = getattr(x, "_pooled2", None)               # 2x2-pooled copy of x supplied by its producer (roi_align)
     if frozen or not torch.is_grad_enabled():
         cur = x
         for bi, bp in enumerate(blocks):
-            cur, _ = _block_forward(cur, bp, False, px0 if bi == 0 else None, blocks[bi + 1].pw[0] if bi + 1 < len(blocks) else None)
+            cur, _ = _block_forward(cur, bp, False, px0 if bi == 0 else None, blocks[bi + 1].pw[0] if bi + 1 < len(blocks) else None,
+                                    out_spec if bi + 1 == len(blocks) else None)
         return cur
-    return ResStageFn.apply(x, blocks[0].w[0], blocks, out_grad_premasked, px0)
+    return ResStageFn.apply(x, blocks[0].w[0], blocks, out_grad_premasked, px0, out_spec)
+
+
+class StackHalvesFn(torch.autograd.Function):
+    """``torch.cat([a, b])`` for two tensors that already ARE the two halves of ``full`` (hip.OutSpec): no copy forward, two
+    views of the gradient backward."""
+
+    @staticmethod
+    def forward(ctx, a, b, full):
+        n = a.shape[0]
+        assert a.data_ptr() == full.data_ptr() and b.data_ptr() == full[n:].data_ptr() and full.shape[0] == 2 * n and a.shape == b.shape
+        ctx.n = n
+        return full.view(full.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.n], g[ctx.n:], None
+
+
+def stack_halves(a, b, full):
+    return StackHalvesFn.apply(a, b, full)
 
 
 def res_stage_attnpool(x, blocks, frozen, ap):

@@ -98,13 +98,13 @@ class ResStage(nn.Sequential):
             self._bp = (dev, [b.params() for b in self])
         return self._bp[1]
 
-    def forward_nhwc(self, x, then_attnpool=None):
+    def forward_nhwc(self, x, then_attnpool=None, out_spec=None):
         """``then_attnpool`` (an AttentionPool2d): returns the pooled embeddings of the stage output instead of the map --
         the RoI head's layer4 -> attnpool composition with the ReLU backward fused (layers.res_stage_attnpool)."""
         frozen = self[0].frozen
         if then_attnpool is not None:
             return layers.res_stage_attnpool(x, self.block_params(), frozen, then_attnpool._params())
-        return layers.res_stage(x, self.block_params(), frozen)
+        return layers.res_stage(x, self.block_params(), frozen, out_spec=out_spec)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))
@@ -207,14 +207,15 @@ class ModifiedResNet(nn.Module):
         x = hip.conv_fwd(x, w3, s3, b3, relu=True, pad=1)
         return hip.avgpool2_fwd(x)
 
-    def forward_nhwc(self, x, want_res5=None):
+    def forward_nhwc(self, x, want_res5=None, res4_spec=None):
         """x: preprocessed NHWC input in the compute dtype.  Returns NHWC feature maps.
-        ``want_res5=False`` skips the full-image layer4 the caller will not read."""
+        ``want_res5=False`` skips the full-image layer4 the caller will not read.  ``res4_spec`` (hip.OutSpec):
+        res4 is written into one half of a buffer shared with a second pass over other images of the same size."""
         with torch.no_grad():
             x = self.stem_nhwc(x)
         x = self.layer1.forward_nhwc(x)
         x = self.layer2.forward_nhwc(x)
-        res4 = self.layer3.forward_nhwc(x)
+        res4 = self.layer3.forward_nhwc(x, out_spec=res4_spec)
         out = {"res4": res4}
         if "res5" in self._out_features and want_res5 is not False:
             out["res5"] = self.layer4.forward_nhwc(res4)

@@ -159,13 +159,17 @@ class GeneralizedRCNN(nn.Module):
         assert sizes == [tuple(i.shape[-2:]) for i in imgs[-n:]], "a sample and its domain twin share one geometry"
         Hp, Wp = max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes)
         x = hip.preprocess(imgs, Hp, Wp, self.pixel_mean_list, self.pixel_std_list, self.compute_dtype)   # always /255: rcnn.py:201
-        f = self.backbone.forward_nhwc(x, want_res5=False)["res4"]
+        spec = shared.get("res4_spec") if shared else None      # the supervised pass left room behind its res4 for the target images'
+        f = self.backbone.forward_nhwc(x, want_res5=False, res4_spec=spec)["res4"]
         gts = [as_instances(x_["instances"]).to(self.device) for x_ in batched_inputs]
         with torch.no_grad():
             if shared is None:
                 props, _ = self.proposal_generator.forward_nhwc(sizes, f[:n].detach(), gts)
             else:
-                f = torch.cat([shared["res4"], f])
+                if spec is not None and spec.used == 2:
+                    f = layers.stack_halves(shared["res4"], f, spec.full)      # already adjacent: no copy
+                else:
+                    f = torch.cat([shared["res4"], f])
                 self.proposal_generator.replay_sampling_draws(shared["counts"])
                 props = shared["proposals"]
             sel_cpu = [torch.randperm(len(p), generator=self.region_generator)[: self.regions_per_image] for p in props]
@@ -254,7 +258,10 @@ class GeneralizedRCNN(nn.Module):
         # supervised: rcnn.py:592-623
         images, sizes = self.preprocess_image(batched_inputs, "image")
         gts = [as_instances(x["instances"]).to(self.device) for x in batched_inputs]
-        res4 = self.backbone.forward_nhwc(images, want_res5=False)["res4"]
+        share = self.share_source_pass and self.use_clip_c4 and self.div_pixel
+        spec = hip.OutSpec() if share else None      # (the region-level branch appends the target images' res4 behind this one)
+        res4 = (self.backbone.forward_nhwc(images, want_res5=False, res4_spec=spec) if share else
+                self.backbone.forward_nhwc(images, want_res5=False))["res4"]
         # The RPN losses wait for host-side anchor sampling: finish them after the box head is in the queue.  Only when the
         # anchor and proposal samplers draw from separate generators (build_trainer seeds one each); with ONE shared stream
         # -- the reference's global RNG, which the oracle parity tests mirror -- the draws keep the reference's order.
@@ -270,8 +277,8 @@ class GeneralizedRCNN(nn.Module):
             _, detector_losses = self.roi_heads(ImageList(None, sizes), {"res4": to_nchw(res4)}, proposals, gts)
         proposal_losses = rpn_losses()
         self._shared = None
-        if self.share_source_pass and self.use_clip_c4 and self.div_pixel:
-            self._shared = {"inputs": batched_inputs, "step": layers._STEP[0], "res4": res4, "sizes": sizes,
+        if share:
+            self._shared = {"inputs": batched_inputs, "step": layers._STEP[0], "res4": res4, "sizes": sizes, "res4_spec": spec,
                             "proposals": proposals, "counts": list(self.proposal_generator.last_counts)}
         losses = {}
         losses.update(detector_losses)
