@@ -255,7 +255,7 @@ def main():
         dom = prof.get(dom_name, {"flops": 0.0, "ms": 0.0, "launches": 0, "bytes": 0.0})
         # HBM traffic per launch of that kernel from the PMC passes (tools/profile_round.sh; FETCH_SIZE x2 + WRITE_SIZE)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if args.batch == 16 and args.dtype == "bf16" and os.path.exists(tpath):   # (measured for the bf16 workload only)
             traffic = json.load(open(tpath)).get(dom_name, {}).get("hbm_bytes_per_launch")
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
@@ -288,7 +288,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom_name + (" (implicit-GEMM conv / linear, forward + input-gradient)" if args.dtype != "fp8" else
                                                                  " (e4m3 implicit-GEMM conv, forward; v_mfma_scale_f32_32x32x64_f8f6f4)"), "achieved": ach,
                          "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r02_traffic.json)",
+                         "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r03_traffic.json)",
                          "by_bound": by_bound,
                          "algorithmic_bytes_per_launch": dom.get("bytes", 0.0) / max(dom["launches"], 1),
                          "algorithmic_flops_per_launch": dom["flops"] / max(dom["launches"], 1),

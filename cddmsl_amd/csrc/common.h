@@ -43,6 +43,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// running max of |x| on the BIT PATTERN (sign cleared): orders like the magnitudes for finite values and puts Inf, then every NaN,
+// above them -- so a non-finite input is not dropped the way fmaxf(m, fabsf(NaN)) drops it, and reaches the recorded maximum
+__device__ __forceinline__ unsigned absmax_bits(unsigned m, float x) {
+  const unsigned u = __builtin_bit_cast(unsigned, x) & 0x7fffffffu;
+  return u > m ? u : m;
+}
+__device__ __forceinline__ unsigned wave_max_u(unsigned v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
+  return v;
+}
+
 static inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? CDDMSL_OK : CDDMSL_ERR_LAUNCH;

@@ -25,7 +25,7 @@ __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float 
 template <bool F32IN>
 __global__ __launch_bounds__(256) void k_quantize_fp8(const char* x, char* y, const float* scale, unsigned* amax_bits, long n8) {
   const float s = scale ? scale[0] : 1.f;
-  float m = 0.f;
+  unsigned m = 0u;                                    // max |x| as a bit pattern: Inf / NaN stay visible (common.h absmax_bits)
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
     float f[8];
     if (F32IN) {
@@ -37,17 +37,19 @@ __global__ __launch_bounds__(256) void k_quantize_fp8(const char* x, char* y, co
       for (int j = 0; j < 4; ++j) { f[2 * j] = bf2f(v[j] & 0xffff); f[2 * j + 1] = bf2f(v[j] >> 16); }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { m = fmaxf(m, fabsf(f[j])); f[j] *= s; }
+    for (int j = 0; j < 8; ++j) { m = absmax_bits(m, f[j]); f[j] *= s; }
     u32x2 o = {pack4_e4m3(f[0], f[1], f[2], f[3]), pack4_e4m3(f[4], f[5], f[6], f[7])};
     ((u32x2*)y)[i] = o;
   }
   if (amax_bits) {                                    // one atomic per block, spread over the slot's 64 words
-    __shared__ float sm[4];
-    m = wave_max(m);
+    __shared__ unsigned sm[4];
+    m = wave_max_u(m);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0)
-      atomicMax(amax_bits + (blockIdx.x & 63), __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));   // non-negative floats order like their bit patterns
+    if (threadIdx.x == 0) {
+      const unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+      atomicMax(amax_bits + (blockIdx.x & 63), a > b ? a : b);   // non-negative floats order like their bit patterns
+    }
   }
 }
 

@@ -1938,7 +1938,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4
   const __amdgpu_buffer_rsrc_t ry8 = mk(p.y8, p.ldy, 1);
   const unsigned vy8 = (unsigned)((wr * 128 + rr) * p.ldy + n);
   const float q8s = emit8 && p.q8 ? p.q8[0] : 1.f;
-  float am8 = 0.f;
+  unsigned am8 = 0u;                                 // max |y| as a bit pattern (common.h absmax_bits): Inf / NaN are recorded, not dropped
   // bf16: residual / mask rows are fetched TWO passes ahead (two register sets, static indices): with one block per CU
   // nothing else hides their HBM latency.  The f32 parity instantiation (twice the registers per row) one pass ahead.
   constexpr int DEPTH = ES == 2 ? 2 : 1;
@@ -2058,7 +2058,7 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4
       // keeps the registers allocated until then (the rows of a pass are otherwise free to interleave).
       if (emit8) {                                  // the e4m3 copy for the consuming convolution (fp8 configuration)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) am8 = fmaxf(am8, fabsf(v[j]));
+        for (int j = 0; j < 8; ++j) am8 = absmax_bits(am8, v[j]);
         const u32x2 o8 = {pack4_e4m3(v[0] * q8s, v[1] * q8s, v[2] * q8s, v[3] * q8s), pack4_e4m3(v[4] * q8s, v[5] * q8s, v[6] * q8s, v[7] * q8s)};
         __builtin_amdgcn_raw_buffer_store_b64(o8, ry8, vy8, (unsigned)((a * 32 + 8 * i) * p.ldy), 0);
         asm volatile("s_nop 4" ::: "memory");
@@ -2086,8 +2086,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4
   pass(std::integral_constant<int, 2>{});
   pass(std::integral_constant<int, 3>{});
   if (emit8 && p.amax8) {                           // (rows past M contribute their bias-only values: an over-estimate at worst)
-    am8 = wave_max(am8);
-    if (lane == 0) atomicMax(p.amax8 + (blockIdx.x & 63), __float_as_uint(am8));
+    am8 = wave_max_u(am8);
+    if (lane == 0) atomicMax(p.amax8 + (blockIdx.x & 63), am8);
   }
 }
 

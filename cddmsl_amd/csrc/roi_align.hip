@@ -92,7 +92,7 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char*
   // y8 (bf16 instantiation, fp8 configuration): a second, OCP e4m3 copy of y = sat(y * q8[0]) for the convolution that consumes
   // the crops, max|y| recorded in amax8[block & 63] -- see cddmsl_conv_fwd_q8
   const float q8s = (y8 && q8) ? q8[0] : 1.f;
-  float am8 = 0.f;
+  unsigned am8 = 0u;                                 // (bit pattern of max |y|: common.h absmax_bits)
   const int nrb = ph / RP;
   const int i0 = (blockIdx.x % nrb) * RP, k = blockIdx.x / nrb;
   RoiGeom g = roi_geom(rois + 5 * (long)k, scale, ph, pw, sampling_ratio, aligned);
@@ -200,7 +200,7 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char*
     if (sizeof(T) == 2 && y8) {
       float f8[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { am8 = fmaxf(am8, fabsf(acc[q])); f8[q] = __builtin_amdgcn_fmed3f(acc[q] * q8s, -448.f, 448.f); }
+      for (int q = 0; q < 8; ++q) { am8 = absmax_bits(am8, acc[q]); f8[q] = __builtin_amdgcn_fmed3f(acc[q] * q8s, -448.f, 448.f); }
       int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8[0], f8[1], 0, false), w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8[4], f8[5], 0, false);
       w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f8[2], f8[3], w0, true); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f8[6], f8[7], w1, true);
       const u32x2 o8 = {(unsigned)w0, (unsigned)w1};
@@ -218,14 +218,14 @@ __global__ void k_roi_align_fwd(const char* x, const float* rois, char* y, char*
   }
   }
   if (sizeof(T) == 2 && y8 && amax8) {              // block-uniform condition
-    __shared__ float sm8[4];
-    am8 = wave_max(am8);
+    __shared__ unsigned sm8[4];
+    am8 = wave_max_u(am8);
     if ((threadIdx.x & 63) == 0) sm8[threadIdx.x >> 6] = am8;
     __syncthreads();
     if (threadIdx.x == 0) {
-      float m = sm8[0];
-      for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) m = fmaxf(m, sm8[wv]);
-      atomicMax(amax8 + (blockIdx.x & 63), __float_as_uint(m));
+      unsigned m = sm8[0];
+      for (int wv = 1; wv < (int)(blockDim.x >> 6); ++wv) m = sm8[wv] > m ? sm8[wv] : m;
+      atomicMax(amax8 + (blockIdx.x & 63), m);
     }
   }
 }

@@ -292,6 +292,10 @@ class SimpleTrainer:
         total = sum(vals)
         if not all(map(lambda v: v == v and abs(v) != float("inf"), [total])):
             raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.iter}!\nloss_dict = {metrics}")
+        from . import layers
+        nf = layers.FP8_SCALES.nonfinite
+        if nf is not None and bool(nf.item()):       # fp8 configuration: e4m3 copies saturate, so an Inf / NaN activation can leave the loss finite
+            raise FloatingPointError(f"An activation or gradient quantised to e4m3 held Inf / NaN at or before iteration={self.iter} (loss_dict = {metrics})")
         self.storage.update(metrics)
         self.storage["total_loss"] = total
         self.storage["data_time"] = data_time

@@ -174,6 +174,15 @@ def _dt(t):
     return DT[t.dtype]
 
 
+def _conv_input_pixels(N, H, W, Ho, Wo, KH, KW, stride, pool):
+    """input pixels a convolution reads at least once (rows x columns its taps cover, per image)"""
+    if pool:
+        return N * min(H, 2 * Ho) * min(W, 2 * Wo)
+    rows = min(H, Ho * min(KH, stride) if stride > KH else (Ho - 1) * stride + KH)
+    cols = min(W, Wo * min(KW, stride) if stride > KW else (Wo - 1) * stride + KW)
+    return N * rows * cols
+
+
 class OutSpec:
     """Where a convolution puts its result when two launches' outputs have to end up adjacent (rows [0, N) and [N, 2N) of ONE
     buffer) without a concatenation copy: the first launch (``full`` None) allocates the double buffer, writes its half and
@@ -239,8 +248,10 @@ def conv_fwd(x, w, scale=None, bias=None, residual=None, relu=False, relu_mask=N
     PROFILE.end(e0, _CONV_KERNEL.get(_L().cddmsl_last_kernel(), "conv_fwd") if e0 is not None else "conv_fwd",
                 2.0 * N * Ho * Wo * Cout * KH * KW * Cin,    # algorithmic 2*M*N*K
                 (N * Ho * Wo, Cout, KH * KW * Cin, KH, int(pool), stride),
-                # algorithmic HBM bytes: every operand once
-                nbytes=float(x.numel() * x.element_size() + w.numel() * w.element_size() + y.numel() * y.element_size()
+                # algorithmic HBM bytes: every operand once -- of x, the pixels the taps reach (a strided 1x1 convolution, e.g. the
+                # attention pool's query projection over every 56th token row, reads one input row per output row, not the tensor)
+                nbytes=float(_conv_input_pixels(N, H, W, Ho, Wo, KH, KW, stride, bool(pool)) * Cin * x.element_size()
+                             + w.numel() * w.element_size() + y.numel() * y.element_size()
                              + (residual.numel() * residual.element_size() if residual is not None else 0)
                              + (relu_mask.numel() * relu_mask.element_size() if relu_mask is not None else 0)))
     if y8 is not None:

@@ -138,9 +138,11 @@ class Fp8Slot:
     def calibrate(self, t):
         if not self.calibrated:
             amax = t.detach().abs().amax().float().view(1)
-            sc = torch.where(amax > 0, hip.FP8_MAX / amax.clamp_min(1e-30), torch.ones_like(amax))
+            ok = torch.isfinite(amax) & (amax > 0)          # (a non-finite tensor keeps scale 1 and raises the table's flag)
+            sc = torch.where(ok, hip.FP8_MAX / amax.clamp(1e-30, 3.0e38), torch.ones_like(amax))
             self.scale.copy_(sc)
             self.deq.copy_(1.0 / sc)
+            FP8_SCALES.note_nonfinite(~torch.isfinite(amax))
             self.calibrated = True
 
     def emit(self):
@@ -158,6 +160,13 @@ class Fp8Scales:
 
     def __init__(self):
         self.buf, self.used = None, 0
+        self.nonfinite = None     # device flag [1]: some quantised tensor held an Inf / NaN (the e4m3 copy itself saturates at +-448,
+        #                           so the loss may stay finite: engine._write_metrics reads this flag next to its NaN / Inf check)
+
+    def note_nonfinite(self, bad):
+        if self.nonfinite is None or self.nonfinite.device != bad.device:
+            self.nonfinite = torch.zeros(1, device=bad.device, dtype=torch.bool)
+        self.nonfinite |= bad.view(-1).any()
 
     def slot(self, device):
         if self.buf is None or self.buf.device != torch.device(device):
@@ -173,8 +182,10 @@ class Fp8Scales:
         if self.buf is None or self.used == 0:
             return
         b = self.buf[: self.used]
-        amax = b[:, 2:].amax(dim=1)
-        new = torch.where(amax > 0, (hip.FP8_MAX * margin) / amax.clamp_min(1e-30), b[:, 0])
+        amax = b[:, 2:].amax(dim=1)                  # (NaN propagates through amax; the kernels record Inf / NaN as such: csrc/common.h absmax_bits)
+        fin = torch.isfinite(amax)
+        self.note_nonfinite(~fin)
+        new = torch.where(fin & (amax > 0), (hip.FP8_MAX * margin) / amax.clamp(1e-30, 3.0e38), b[:, 0])   # a non-finite maximum keeps the previous scale
         b[:, 0] = new
         b[:, 1] = 1.0 / new
         b[:, 2:] = 0.0
@@ -939,9 +950,14 @@ def _fp8_const(value, device):
     return _FP8_CONST[k]
 
 
+def fp8_unit_rows(wn):
+    """e4m3 copy of unit-norm rows at the fixed scale 448 (the format's whole range)"""
+    return hip.quantize_fp8(wn.contiguous(), _fp8_const(hip.FP8_MAX, wn.device))
+
+
 class CosineLogitsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wn, temperature, fp8=False):
+    def forward(ctx, x, wn, temperature, fp8=False, wn8=None):
         x = x.contiguous()
         if fp8 and x.shape[1] % 64 == 0 and wn.shape[0] <= 32:
             # the region x text-embedding contraction on e4m3 operands (BASELINE.json configs[4]): rows are unit vectors, so a fixed
@@ -949,11 +965,9 @@ class CosineLogitsFn(torch.autograd.Function):
             # backward is the exact-f32 one (straight-through: the quantisation is not differentiated).
             xn, inv = hip.l2norm_fwd(x, 1e-12)
             unit = _fp8_const(hip.FP8_MAX, x.device)
-            key = (wn.data_ptr(), wn._version)
-            c = _FP8_CONST.get("wn")
-            if c is None or c[0] != key:
-                _FP8_CONST["wn"] = c = (key, hip.quantize_fp8(wn.contiguous(), unit))
-            dot = hip.fp8_dot_nt(hip.quantize_fp8(xn, unit), c[1], _fp8_const(1.0 / (hip.FP8_MAX * hip.FP8_MAX * temperature), x.device))
+            if wn8 is None:          # (callers that own the embeddings pass their cached copy: no process-wide cache keyed by address)
+                wn8 = fp8_unit_rows(wn)
+            dot = hip.fp8_dot_nt(hip.quantize_fp8(xn, unit), wn8, _fp8_const(1.0 / (hip.FP8_MAX * hip.FP8_MAX * temperature), x.device))
             scores = torch.cat([dot, torch.zeros(x.shape[0], 1, device=x.device, dtype=torch.float32)], dim=1)
         else:
             scores, inv = hip.cosine_logits_fwd(x, wn, temperature)
@@ -964,11 +978,11 @@ class CosineLogitsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ds):
         x, wn, inv = ctx.saved_tensors
-        return hip.cosine_logits_bwd(ds, x.contiguous(), wn, inv, ctx.t), None, None, None
+        return hip.cosine_logits_bwd(ds, x.contiguous(), wn, inv, ctx.t), None, None, None, None
 
 
-def cosine_logits(x, wn, temperature, fp8=False):
-    return CosineLogitsFn.apply(x, wn, temperature, fp8)
+def cosine_logits(x, wn, temperature, fp8=False, wn8=None):
+    return CosineLogitsFn.apply(x, wn, temperature, fp8, wn8)
 
 
 class ContrastiveFn(torch.autograd.Function):

@@ -181,7 +181,13 @@ class FastRCNNOutputLayers(nn.Module):
         """x [R, 1024] f32 -> (scores [R, K+1] f32, deltas [R, 4K] f32)   fast_rcnn.py:529-572"""
         xt = x.to(self.compute_dtype)
         if self.use_clip_cls_emb:
-            scores = layers.cosine_logits(x, self._text_emb(), self.temperature, fp8=self.fp8)
+            wn = self._text_emb()
+            wn8 = None
+            if self.fp8:        # e4m3 copy of the unit-norm class embeddings, kept on the module next to the normalised ones (same key)
+                if getattr(self, "_wn8", None) is None or self._wn8[0] is not wn:
+                    self._wn8 = (wn, layers.fp8_unit_rows(wn))
+                wn8 = self._wn8[1]
+            scores = layers.cosine_logits(x, wn, self.temperature, fp8=self.fp8, wn8=wn8)
             deltas = layers.linear(xt, self.bbox_pred.pw(), self.bbox_pred.bias, out_f32=True)
             return scores, deltas
         # plain classifier: cls_score (K+1) and bbox_pred (4K) as ONE padded GEMM (row widths must be whole 16-B chunks)

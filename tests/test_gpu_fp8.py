@@ -156,3 +156,29 @@ def test_fp8_step_is_close_to_f32_step_with_forced_indices(monkeypatch):
         assert abs(l8[k] - f32_losses[k]) <= 6e-2 * abs(f32_losses[k]) + 5e-3, (k, l8[k], f32_losses[k])
     # (the lowest cosines belong to the RPN's box-delta head: its L1 loss has a sign() gradient, which flips on small changes)
     assert errs[0][0] >= 0.92, errs[0]
+
+
+def test_fp8_quantisation_records_non_finite_inputs():
+    """``fmaxf(m, fabsf(NaN))`` dropped NaN from the recorded maximum and the saturating e4m3 conversion turns Inf / NaN
+    into +-448, so a diverged tensor could leave every loss finite.  The maximum is now taken on the bit pattern (Inf / NaN order
+    above every finite value), ``Fp8Scales.roll`` keeps the previous scale for such a slot and raises the table's device flag,
+    which ``SimpleTrainer._write_metrics`` reads."""
+    from cddmsl_amd import hip, layers
+    sc = layers.Fp8Scales()
+    old, layers.FP8_SCALES = layers.FP8_SCALES, sc
+    try:
+        s1, s2 = sc.slot("cuda"), sc.slot("cuda")
+        x = torch.randn(4096, device="cuda").bfloat16()
+        hip.quantize_fp8(x, s1.scale, s1.amax)
+        bad = x.clone()
+        bad[77] = float("nan")
+        bad[99] = float("inf")
+        y8 = hip.quantize_fp8(bad, s2.scale, s2.amax)
+        assert int(y8[77]) in (0x7e, 0xfe, 0x7f, 0xff) or True      # (whatever the saturated byte is, the RECORD is what matters)
+        assert bool(torch.isfinite(s1.amax.max())) and not bool(torch.isfinite(s2.amax.max()))
+        before = float(s2.scale)
+        sc.roll()
+        assert float(s2.scale) == before and bool(torch.isfinite(s1.scale)) and float(s1.scale) != 1.0
+        assert sc.nonfinite is not None and bool(sc.nonfinite.item())
+    finally:
+        layers.FP8_SCALES = old

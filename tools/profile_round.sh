@@ -10,9 +10,9 @@
 #   3. tools/shape_profile.py                                                   -> <tag>_shape_profile.txt
 #   4. tools/clock_probe.hip (in-kernel clock of an MFMA-dense loop)            -> <tag>_clock_probe.txt
 #   5. tools/hbm_probe.hip (what plain streaming kernels sustain on this box)   -> <tag>_hbm_probe.txt
-# usage: bash tools/profile_round.sh r02
+# usage: bash tools/profile_round.sh r03
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
