@@ -746,4 +746,4 @@ extern "C" int cddmsl_sgd_clip_step(float** params, const float** grads, float**
 }
 
 // ABI version of include/cddmsl_hip.h (bumped when an entry point's signature changes); 2 = round 2 (bring-up probe removed)
-extern "C" int cddmsl_abi_version() { return 2; }
+extern "C" int cddmsl_abi_version() { return 3; }

@@ -30,7 +30,7 @@ def test_exports_match_header(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "cddmsl_amd", "libcddmsl_hip.so")], text=True)
     exported = sorted(set(re.findall(r"\bT (cddmsl_\w+)", out)))
     assert exported == names, set(exported) ^ set(names)
-    assert lib.cddmsl_abi_version() == 2
+    assert lib.cddmsl_abi_version() == 3
 
 
 def test_header_compiles_as_c():
