@@ -169,7 +169,10 @@ class Fp8Scales:
         self.nonfinite |= bad.view(-1).any()
 
     def slot(self, device):
-        if self.buf is None or self.buf.device != torch.device(device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:       # ("cuda" names the current device: compare like with like)
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self.buf is None or self.buf.device != device:
             self.buf = torch.zeros(self.CAP, self.W, device=device, dtype=torch.float32)
             self.buf[:, :2] = 1.0
             self.used = 0
