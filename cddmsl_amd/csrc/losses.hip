@@ -436,3 +436,100 @@ extern "C" int cddmsl_focal_ce_bwd(const float* logits, const long* target, cons
   k_focal_ce_bwd<<<dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(logits, target, probs, gscale, dlogits, R, C, gamma, bg_class, bg_weight);
   return launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Losses over SAMPLED rows, index lists known (no dense pass, no boolean masks):
+//   RPN  (modeling/proposal_generator/rpn.py:365-429, box_regression.py:229-270; smooth-L1 beta 0 = L1):
+//        loss_cls = sum over the sampled anchors of BCE-with-logits(logit, label) * inv_norm      (label 1 = positive, 0 = negative)
+//        loss_loc = sum over the positives of |delta - get_deltas(anchor, matched gt box)| * inv_norm
+//   box head (modeling/roi_heads/fast_rcnn.py:646-689): sum over the foreground rows of |delta[class-specific 4] - get_deltas(proposal, gt)| * inv_norm
+// One block: a few thousand rows at most, summed in a fixed order (deterministic).  The backward scatters into caller-zeroed
+// gradient tensors: d/dlogit = (sigmoid(x) - y) g inv_norm, d/ddelta = sign(delta - target) g inv_norm (0 at equality, as torch.abs).
+namespace {
+struct BoxW { float wx, wy, ww, wh; };
+// Box2BoxTransform.get_deltas (box_regression.py:42-75), same expression order as cddmsl_amd/modeling/rpn.py::get_deltas
+__device__ __forceinline__ void get_deltas4(const float* s, const float* t, BoxW w, float* d) {
+  const float sw = s[2] - s[0], sh = s[3] - s[1];
+  const float sx = s[0] + 0.5f * sw, sy = s[1] + 0.5f * sh;
+  const float tw = t[2] - t[0], th = t[3] - t[1];
+  const float tx = t[0] + 0.5f * tw, ty = t[1] + 0.5f * th;
+  d[0] = w.wx * (tx - sx) / sw; d[1] = w.wy * (ty - sy) / sh;
+  d[2] = w.ww * logf(tw / sw); d[3] = w.wh * logf(th / sh);
+}
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void k_rpn_losses(const float* logits, const float* deltas, const long* pos, int npos, const long* neg, int nneg,
+                                                     const long* midx, const float* gt, const long* gt_off, const float* anchors, long A, BoxW w,
+                                                     float inv_norm, float* out2, const float* gout2, float* dlogits, float* ddeltas) {
+  __shared__ float red[4];
+  const bool bwd = gout2 != nullptr;
+  const float gc = bwd ? gout2[0] * inv_norm : 0.f, gl = bwd ? gout2[1] * inv_norm : 0.f;
+  float cls = 0.f, loc = 0.f;
+  for (int i = threadIdx.x; i < npos + nneg; i += blockDim.x) {
+    const bool is_pos = i < npos;
+    const long r = is_pos ? pos[i] : neg[i - npos];
+    const float x = logits[r], y = is_pos ? 1.f : 0.f;
+    if (!bwd) cls += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));          // binary_cross_entropy_with_logits
+    else dlogits[r] = (1.f / (1.f + expf(-x)) - y) * gc;
+    if (is_pos) {
+      const long img = r / A, a = r - img * A;
+      float d[4];
+      get_deltas4(anchors + 4 * a, gt + 4 * (midx[r] + gt_off[img]), w, d);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float e = deltas[4 * r + c] - d[c];
+        if (!bwd) loc += fabsf(e); else ddeltas[4 * r + c] = sgn(e) * gl;
+      }
+    }
+  }
+  if (!bwd) {
+    cls = block_sum(cls, red);
+    loc = block_sum(loc, red);
+    if (threadIdx.x == 0) { out2[0] = cls * inv_norm; out2[1] = loc * inv_norm; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_box_l1(const float* deltas, int ld, const long* fg, int nfg, const long* cls, const float* src, const float* tgt,
+                                                BoxW w, float inv_norm, float* out1, const float* gout1, float* ddeltas) {
+  __shared__ float red[4];
+  const bool bwd = gout1 != nullptr;
+  const float g = bwd ? gout1[0] * inv_norm : 0.f;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nfg; i += blockDim.x) {
+    const long r = fg[i], c0 = cls ? 4 * cls[r] : 0;
+    float d[4];
+    get_deltas4(src + 4 * r, tgt + 4 * r, w, d);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float e = deltas[r * ld + c0 + c] - d[c];
+      if (!bwd) acc += fabsf(e); else ddeltas[r * ld + c0 + c] = sgn(e) * g;
+    }
+  }
+  if (!bwd) {
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) out1[0] = acc * inv_norm;
+  }
+}
+}  // namespace
+
+// logits [N*A] f32, deltas [N*A][4] f32, pos / neg: global anchor indices (image * A + anchor) of the sampled anchors, midx [N*A] the
+// matched gt index per anchor (within its image), gt [G][4] all images' boxes, gt_off [N] first row of each image's boxes,
+// anchors [A][4].  out2 = (loss_rpn_cls, loss_rpn_loc).  Backward (gout2 given): dlogits / ddeltas must be zero-filled by the caller.
+extern "C" int cddmsl_rpn_losses(const float* logits, const float* deltas, const long* pos, int npos, const long* neg, int nneg, const long* midx,
+                                 const float* gt, const long* gt_off, const float* anchors, long A, float wx, float wy, float ww, float wh,
+                                 float inv_norm, float* out2, const float* gout2, float* dlogits, float* ddeltas, void* stream) {
+  if (npos < 0 || nneg < 0 || A <= 0 || (gout2 ? (!dlogits || !ddeltas) : !out2)) return CDDMSL_ERR_ARG;
+  hipLaunchKernelGGL(k_rpn_losses, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, deltas, pos, npos, neg, nneg, midx, gt, gt_off, anchors, A,
+                     BoxW{wx, wy, ww, wh}, inv_norm, out2, gout2, dlogits, ddeltas);
+  return launch_status();
+}
+
+// deltas [R][ld] f32, fg [nfg] row indices, cls [R] (nullable: class-agnostic, column 0) the class whose 4 columns a row trains,
+// src / tgt [R][4] proposal and ground-truth boxes.  out1 = sum |delta - target| * inv_norm.  Backward: ddeltas zero-filled by the caller.
+extern "C" int cddmsl_box_l1(const float* deltas, int ld, const long* fg, int nfg, const long* cls, const float* src, const float* tgt, float wx,
+                             float wy, float ww, float wh, float inv_norm, float* out1, const float* gout1, float* ddeltas, void* stream) {
+  if (nfg < 0 || ld < 4 || (gout1 ? !ddeltas : !out1)) return CDDMSL_ERR_ARG;
+  hipLaunchKernelGGL(k_box_l1, dim3(1), dim3(256), 0, (hipStream_t)stream, deltas, ld, fg, nfg, cls, src, tgt, BoxW{wx, wy, ww, wh}, inv_norm, out1,
+                     gout1, ddeltas);
+  return launch_status();
+}

@@ -74,6 +74,8 @@ def _L():
         L.cddmsl_attn_small_bwd.argtypes = [vp] * 7 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_attn_tokens_fwd_mask.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_attnpool_dx.argtypes = [vp] * 6 + [ci] * 6 + [vp]
+        L.cddmsl_rpn_losses.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, c_long, cf, cf, cf, cf, cf, vp, vp, vp, vp, vp]
+        L.cddmsl_box_l1.argtypes = [vp, ci, vp, ci, vp, vp, vp, cf, cf, cf, cf, cf, vp, vp, vp, vp]
         L.cddmsl_attn_last_fwd.argtypes = [vp] * 4 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_attn_last_bwd.argtypes = [vp] * 6 + [ci] * 8 + [cf, ci, vp]
         L.cddmsl_contrastive_fwd.argtypes = [vp] * 4 + [ci, ci, vp]
@@ -488,6 +490,43 @@ def attn_tokens_fwd_mask(x, pos, tp=None):
     mbits = torch.empty((K, C), device=x.device, dtype=torch.int64)
     check(_L().cddmsl_attn_tokens_fwd_mask(ptr(x), ptr(pos), ptr(tok), ptr(mbits), K, P, tp, C, _dt(x), stream_ptr()), "cddmsl_attn_tokens_fwd_mask")
     return tok, mbits
+
+
+def rpn_losses(logits, deltas, pos, neg, midx, gt, gt_off, anchors, weights, inv_norm, gout=None):
+    """forward: -> [2] f32 (loss_rpn_cls, loss_rpn_loc); backward (gout [2]): -> (dlogits, ddeltas), zero except at the sampled anchors"""
+    require_cuda(logits, deltas, pos, neg, midx, gt, gt_off, anchors)
+    for t in (logits, deltas, gt, anchors):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    for t in (pos, neg, midx, gt_off):
+        assert t.dtype == torch.int64 and t.is_contiguous()
+    A = anchors.shape[0]
+    assert deltas.numel() == 4 * logits.numel() and midx.numel() == logits.numel()
+    args = (ptr(logits), ptr(deltas), ptr(pos), pos.numel(), ptr(neg), neg.numel(), ptr(midx), ptr(gt), ptr(gt_off), ptr(anchors), A,
+            *[float(w) for w in weights], float(inv_norm))
+    if gout is None:
+        out = torch.empty(2, device=logits.device, dtype=torch.float32)
+        check(_L().cddmsl_rpn_losses(*args, ptr(out), None, None, None, stream_ptr()), "cddmsl_rpn_losses")
+        return out
+    dl, dd = torch.zeros_like(logits), torch.zeros_like(deltas)
+    g = gout.contiguous().float()
+    check(_L().cddmsl_rpn_losses(*args, None, ptr(g), ptr(dl), ptr(dd), stream_ptr()), "cddmsl_rpn_losses(backward)")
+    return dl, dd
+
+
+def box_l1(deltas, fg, cls, src, tgt, weights, inv_norm, gout=None):
+    """forward: -> [1] f32 sum_{fg} |deltas[r, 4 cls[r]..+4] - get_deltas(src[r], tgt[r])| * inv_norm; backward (gout [1]): -> ddeltas"""
+    require_cuda(deltas, fg, src, tgt)
+    assert deltas.dtype == torch.float32 and deltas.dim() == 2 and deltas.is_contiguous() and fg.dtype == torch.int64 and fg.is_contiguous()
+    assert src.dtype == tgt.dtype == torch.float32 and src.is_contiguous() and tgt.is_contiguous() and (cls is None or (cls.dtype == torch.int64 and cls.is_contiguous()))
+    args = (ptr(deltas), deltas.shape[1], ptr(fg), fg.numel(), ptr(cls), ptr(src), ptr(tgt), *[float(w) for w in weights], float(inv_norm))
+    if gout is None:
+        out = torch.empty(1, device=deltas.device, dtype=torch.float32)
+        check(_L().cddmsl_box_l1(*args, ptr(out), None, None, stream_ptr()), "cddmsl_box_l1")
+        return out
+    dd = torch.zeros_like(deltas)
+    g = gout.contiguous().float().view(1)
+    check(_L().cddmsl_box_l1(*args, None, ptr(g), ptr(dd), stream_ptr()), "cddmsl_box_l1(backward)")
+    return dd
 
 
 def attnpool_dx_ok(K, H, P, TP, C, dtype):

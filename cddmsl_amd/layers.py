@@ -1086,6 +1086,48 @@ def focal_cross_entropy(logits, target, gamma, bg_class, bg_weight):
     return FocalCEFn.apply(logits, target, float(gamma or 0.0), int(bg_class), float(1.0 if bg_weight is None else bg_weight))
 
 
+class RpnLossesFn(torch.autograd.Function):
+    """(loss_rpn_cls, loss_rpn_loc) of RPN.losses (rpn.py:365-429) over the SAMPLED anchors only -- their index lists are known --
+    as one kernel per direction instead of a dense BCE over all N x A anchors and ~35 gather / arithmetic launches."""
+
+    @staticmethod
+    def forward(ctx, logits, deltas, pos, neg, midx, gt, gt_off, anchors, weights, inv_norm):
+        logits, deltas = logits.contiguous(), deltas.contiguous()
+        ctx.save_for_backward(logits, deltas, pos, neg, midx, gt, gt_off, anchors)
+        ctx.cfg = (weights, inv_norm)
+        return hip.rpn_losses(logits, deltas, pos, neg, midx, gt, gt_off, anchors, weights, inv_norm)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, deltas, pos, neg, midx, gt, gt_off, anchors = ctx.saved_tensors
+        dl, dd = hip.rpn_losses(logits, deltas, pos, neg, midx, gt, gt_off, anchors, ctx.cfg[0], ctx.cfg[1], gout=g)
+        return dl, dd, None, None, None, None, None, None, None, None
+
+
+def rpn_losses(logits, deltas, pos, neg, midx, gt, gt_off, anchors, weights, inv_norm):
+    return RpnLossesFn.apply(logits, deltas, pos, neg, midx, gt, gt_off, anchors, tuple(weights), float(inv_norm))
+
+
+class BoxL1Fn(torch.autograd.Function):
+    """sum over the foreground rows of |class-specific deltas - get_deltas(proposal, gt box)| * inv_norm (fast_rcnn.py:646-689)"""
+
+    @staticmethod
+    def forward(ctx, deltas, fg, cls, src, tgt, weights, inv_norm):
+        deltas = deltas.contiguous()
+        ctx.save_for_backward(deltas, fg, cls, src, tgt)
+        ctx.cfg = (weights, inv_norm)
+        return hip.box_l1(deltas, fg, cls, src, tgt, weights, inv_norm).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        deltas, fg, cls, src, tgt = ctx.saved_tensors
+        return hip.box_l1(deltas, fg, cls, src, tgt, ctx.cfg[0], ctx.cfg[1], gout=g), None, None, None, None, None, None
+
+
+def box_l1(deltas, fg, cls, src, tgt, weights, inv_norm):
+    return BoxL1Fn.apply(deltas, fg, cls, src.contiguous(), tgt.contiguous(), tuple(weights), float(inv_norm))
+
+
 class MeanPoolFn(torch.autograd.Function):
     """box_features.mean(dim=[2, 3]) of Res5ROIHeads (roi_heads.py:487): [K,h,w,C] T -> [K,C] f32"""
 

@@ -215,9 +215,13 @@ class FastRCNNOutputLayers(nn.Module):
             fg = to_device_async(torch.cat(idx), gt_classes.device)
         else:
             fg = torch.nonzero((gt_classes >= 0) & (gt_classes < self.num_classes), as_tuple=True)[0]
-        fg_pred = deltas.view(-1, self.num_classes, 4)[fg, gt_classes[fg]]
-        gt_d = get_deltas(pboxes[fg], gboxes[fg], self.box_weights)
-        loss_box = torch.abs(fg_pred - gt_d).sum() / max(gt_classes.numel(), 1.0)
+        if deltas.is_cuda and deltas.dtype == torch.float32 and deltas.shape[1] == 4 * self.num_classes:
+            # one kernel per direction over the foreground index list (class-specific columns picked inside)
+            loss_box = layers.box_l1(deltas, fg, gt_classes, pboxes.float(), gboxes.float(), self.box_weights, 1.0 / max(gt_classes.numel(), 1.0))
+        else:
+            fg_pred = deltas.view(-1, self.num_classes, 4)[fg, gt_classes[fg]]
+            gt_d = get_deltas(pboxes[fg], gboxes[fg], self.box_weights)
+            loss_box = torch.abs(fg_pred - gt_d).sum() / max(gt_classes.numel(), 1.0)
         out = {"loss_cls": loss_cls, "loss_box_reg": loss_box}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
 

@@ -245,7 +245,7 @@ class RPN(nn.Module):
         flat.fill_(-1)
         flat.index_fill_(0, pos_g, 1)               # (``flat[pos_g] = 1`` stages its scalar through a synchronizing host-to-device copy)
         flat.index_fill_(0, neg_g, 0)
-        self.last_pos_global = pos_g
+        self.last_pos_global, self.last_neg_global = pos_g, neg_g
         return labels, matched
 
     def label_and_sample_anchors(self, anchors, gt_instances):
@@ -266,14 +266,24 @@ class RPN(nn.Module):
         gl = labels
         n, A = gl.shape
         midx, gts = matched
+        pos_g = self.last_pos_global
+        gt_off = to_device_async(torch.tensor([0] + [len(g) for g in gts]).cumsum(0)[:-1], gl.device)
+        gt_cat = torch.cat(gts) if sum(len(g) for g in gts) else torch.zeros((1, 4), device=gl.device)
+        norm = self.batch_size_per_image * n
+        if logits.is_cuda and logits.dtype == torch.float32 and getattr(self, "last_neg_global", None) is not None:
+            # both losses over the sampled anchors' index lists (known on the host side of the sampling: no mask, no dense pass)
+            neg_g = self.last_neg_global
+            self.storage["rpn/num_pos_anchors"] = pos_g.numel() / n      # (= (labels == 1).sum() / n: every positive label IS a sampled index)
+            self.storage["rpn/num_neg_anchors"] = neg_g.numel() / n
+            both = layers.rpn_losses(logits.reshape(-1), deltas.reshape(-1, 4), pos_g, neg_g, midx.view(-1), gt_cat.float().contiguous(), gt_off,
+                                     anchors, self.weights, 1.0 / norm)
+            out = {"loss_rpn_cls": both[0], "loss_rpn_loc": both[1]}
+            return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
         pos = gl == 1
         self.storage["rpn/num_pos_anchors"] = pos.sum() / n
         self.storage["rpn/num_neg_anchors"] = (gl == 0).sum() / n
         # positives = the sampled foreground picks (known index list, image by image in pick order): no nonzero, no host sync
-        pos_g = self.last_pos_global
         img, a = torch.div(pos_g, A, rounding_mode="floor"), pos_g % A
-        gt_off = to_device_async(torch.tensor([0] + [len(g) for g in gts]).cumsum(0)[:-1], gl.device)
-        gt_cat = torch.cat(gts) if sum(len(g) for g in gts) else torch.zeros((1, 4), device=gl.device)
         mbox = gt_cat[midx.view(-1)[pos_g] + gt_off[img]]          # an image without boxes has no positives, so no row of it is read
         gt_d = get_deltas(anchors[a], mbox, self.weights)
         loc = torch.abs(deltas.reshape(-1, 4)[pos_g] - gt_d).sum()

@@ -223,6 +223,17 @@ int cddmsl_focal_ce_bwd(const float* logits, const long* target, const float* pr
 int cddmsl_contrastive_fwd(const float* S, float* rlse, float* clse, float* loss, int n, int ld, void* stream);
 int cddmsl_contrastive_bwd(const float* S, const float* rlse, const float* clse, const float* gloss, float* dS, int n, int ld,
                            void* stream);
+/* Losses over SAMPLED rows with known index lists (no dense pass, no boolean-mask gathers):
+ *   cddmsl_rpn_losses: RPN.losses (modeling/proposal_generator/rpn.py:365-429; _dense_box_regression_loss box_regression.py:229-270, smooth-L1 beta 0):
+ *     out2 = (sum_{sampled} BCE-with-logits, sum_{positives} |delta - get_deltas(anchor, matched gt)|) * inv_norm.  logits [N*A], deltas [N*A][4],
+ *     pos / neg = global anchor indices (image * A + anchor), midx [N*A] matched gt index within the image, gt [G][4], gt_off [N], anchors [A][4].
+ *   cddmsl_box_l1: FastRCNNOutputLayers.box_reg_loss (modeling/roi_heads/fast_rcnn.py:646-689): out1 = sum_{fg rows} |delta[4 cls[r] ..] - get_deltas(src, tgt)| * inv_norm;
+ *     cls nullable (class-agnostic).  Backward = the same entry point with gout given: gradients are scattered into CALLER-ZEROED tensors. */
+int cddmsl_rpn_losses(const float* logits, const float* deltas, const long* pos, int npos, const long* neg, int nneg, const long* midx,
+                      const float* gt, const long* gt_off, const float* anchors, long A, float wx, float wy, float ww, float wh, float inv_norm,
+                      float* out2, const float* gout2, float* dlogits, float* ddeltas, void* stream);
+int cddmsl_box_l1(const float* deltas, int ld, const long* fg, int nfg, const long* cls, const float* src, const float* tgt, float wx, float wy,
+                  float ww, float wh, float inv_norm, float* out1, const float* gout1, float* ddeltas, void* stream);
 
 /* ---- elementwise: preprocessing (modeling/meta_arch/rcnn.py:161-179,758-768, structures/image_list.py:72-124),
  * AvgPool2d(2) (clip_backbone.py:36,46,147), ReLU backward, column sums, fused clip+SGD (solver/build.py:59-130) -- */
