@@ -2691,6 +2691,7 @@ template <typename T> void launch_fwd2(const ConvArgs& a, dim3 grid, hipStream_t
 
 template <typename T, bool TAPS> void launch256_main(const ConvArgs& a, dim3 grid, hipStream_t st, int epi);
 // the 256x256 kernel's epilogue variant (template parameter EPI): compile-time operand set for bf16 outputs, run-time flags otherwise
+constexpr int TAIL_FRAC_DEFAULT = 8;
 template <typename T, bool TAPS> void launch256(const ConvArgs& a, dim3 grid, hipStream_t st) {
   if (sizeof(T) == 4 || a.out_f32 || a.res_f32 || a.y8) { hipLaunchKernelGGL((k_conv_fwd256<T, TAPS, false, -1>), grid, dim3(512), 0, st, a); return; }
   const int epi = (a.residual ? 1 : 0) | (a.relu_mask ? 2 : 0);
@@ -2702,7 +2703,9 @@ template <typename T, bool TAPS> void launch256(const ConvArgs& a, dim3 grid, hi
     const int ncu = persistent_blocks_raw();
     const int tiles = (int)grid.x, rem = ncu > 0 ? tiles % ncu : 0, nktot = a.Kc >> 3;
     const char* et = getenv("CDDMSL_TAIL_SPLIT");
-    if (!(et && atoi(et) == 0) && grid.y == 1 && tiles > ncu && rem > 0 && rem * 8 <= ncu && nktot >= 16 && g_ws) {
+    const char* ef = getenv("CDDMSL_TAIL_FRAC");                 // the last round counts as "nearly empty" below 1 / FRAC of the CUs
+    const int frac = ef ? (atoi(ef) > 0 ? atoi(ef) : 8) : TAIL_FRAC_DEFAULT;
+    if (!(et && atoi(et) == 0) && grid.y == 1 && tiles > ncu && rem > 0 && rem * frac <= ncu && nktot >= 16 && g_ws) {
       int S = ncu / rem;
       if (S > nktot / 2) S = nktot / 2;
       { const char* es = getenv("CDDMSL_TAIL_MAXS"); if (es && S > atoi(es)) S = atoi(es); }      // (A/B knob)
