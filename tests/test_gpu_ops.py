@@ -812,3 +812,61 @@ def test_attention_pool_input_gradient_fused_epilogue(premask, monkeypatch):
         assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-6), n
     if premask:
         assert bool((res["1"][0][x0.float() <= 0] == 0).all())
+
+
+def test_sampled_loss_kernels_match_torch():
+    """cddmsl_rpn_losses / cddmsl_box_l1 (RPN.losses rpn.py:365-429, box_reg_loss fast_rcnn.py:646-689 over the sampled index lists)
+    against the torch expressions they replace -- the dense weighted BCE + gathered L1 of round 2 -- values and gradients; an image
+    without ground truth, no positives at all, and the class-agnostic form."""
+    from cddmsl_amd import layers
+    from cddmsl_amd.modeling.rpn import get_deltas
+    g = torch.Generator().manual_seed(31)
+    N, A = 3, 500
+    anchors = torch.rand(A, 4, generator=g) * 200
+    anchors[:, 2:] += anchors[:, :2] + 8
+    gts = [torch.tensor([[10.0, 20.0, 120.0, 160.0], [50.0, 40.0, 90.0, 200.0]]), torch.zeros(0, 4), torch.tensor([[5.0, 5.0, 60.0, 70.0]])]
+    gt_cat = torch.cat(gts).cuda()
+    gt_off = torch.tensor([0, 2, 2]).cuda()
+    midx = torch.randint(0, 2, (N, A), generator=g)
+    midx[1:] = 0
+    pos = torch.tensor([3, 17, 402, 2 * A + 9, 2 * A + 77])                         # images 0 and 2 only (image 1 has no boxes)
+    neg = torch.cat([torch.randperm(A, generator=g)[:40] + 20, A + torch.randperm(A, generator=g)[:30], 2 * A + 100 + torch.randperm(300, generator=g)[:20]])
+    neg = neg[~torch.isin(neg, pos)]
+    logits = torch.randn(N, A, generator=g).cuda().requires_grad_(True)
+    deltas = torch.randn(N, A, 4, generator=g).cuda().requires_grad_(True)
+    w, norm = (1.0, 1.0, 1.0, 1.0), 256.0 * N
+    both = layers.rpn_losses(logits.reshape(-1), deltas.reshape(-1, 4), pos.cuda(), neg.cuda(), midx.cuda().view(-1), gt_cat, gt_off, anchors.cuda(), w, 1.0 / norm)
+    (both[0] * 1.5 + both[1] * 0.7).backward()
+    lg2, dl2 = logits.detach().clone().requires_grad_(True), deltas.detach().clone().requires_grad_(True)
+    lab = torch.full((N * A,), -1.0)
+    lab[pos], lab[neg] = 1.0, 0.0
+    lab = lab.cuda()
+    cls = F.binary_cross_entropy_with_logits(lg2.view(-1), lab.clamp(min=0), weight=(lab >= 0).float(), reduction="sum") / norm
+    pc = pos.cuda()
+    mb = gt_cat[midx.cuda().view(-1)[pc] + gt_off[pc // A]]
+    loc = (dl2.view(-1, 4)[pc] - get_deltas(anchors.cuda()[pc % A], mb, w)).abs().sum() / norm
+    (cls * 1.5 + loc * 0.7).backward()
+    assert torch.allclose(both[0], cls, rtol=1e-5) and torch.allclose(both[1], loc, rtol=1e-5)
+    assert torch.allclose(logits.grad, lg2.grad, rtol=1e-5, atol=1e-9) and torch.allclose(deltas.grad, dl2.grad, rtol=1e-5, atol=1e-9)
+    empty = torch.zeros(0, dtype=torch.int64).cuda()
+    z = layers.rpn_losses(logits.detach().reshape(-1), deltas.detach().reshape(-1, 4), empty, empty, midx.cuda().view(-1), gt_cat, gt_off, anchors.cuda(), w, 1.0)
+    assert float(z[0]) == 0.0 and float(z[1]) == 0.0
+    # box head: class-specific columns of the foreground rows
+    R, Kc = 64, 20
+    d = torch.randn(R, 4 * Kc, generator=g).cuda().requires_grad_(True)
+    cls_id = torch.randint(0, Kc + 1, (R,), generator=g).cuda()
+    fg = torch.nonzero(cls_id < Kc).flatten()
+    src = torch.rand(R, 4, generator=g).cuda() * 100
+    src[:, 2:] += src[:, :2] + 4
+    tgt = torch.rand(R, 4, generator=g).cuda() * 100
+    tgt[:, 2:] += tgt[:, :2] + 4
+    bw = (10.0, 10.0, 5.0, 5.0)
+    l1 = layers.box_l1(d, fg, cls_id, src, tgt, bw, 1.0 / R)
+    l1.backward()
+    d2 = d.detach().clone().requires_grad_(True)
+    ref = (d2.view(R, Kc, 4)[fg, cls_id[fg]] - get_deltas(src[fg], tgt[fg], bw)).abs().sum() / R
+    ref.backward()
+    assert torch.allclose(l1, ref, rtol=1e-5) and torch.allclose(d.grad, d2.grad, rtol=1e-5, atol=1e-9)
+    d3 = torch.randn(R, 4, generator=g).cuda()
+    agn = layers.box_l1(d3, fg, None, src, tgt, bw, 1.0)
+    assert torch.allclose(agn, (d3[fg] - get_deltas(src[fg], tgt[fg], bw)).abs().sum(), rtol=1e-5)
