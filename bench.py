@@ -85,12 +85,38 @@ def cpu_baseline(height, width, threads, batch=2, timed=3, budget_s=150.0):
                       f"timed steps ({', '.join('%.1f' % t for t in times)} s)"}
 
 
+def visible_gpu_count(env=os.environ):
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the parent of the ranks must not hold a device): the KFD
+    topology's nodes with SIMDs (CPU nodes have simd_count 0), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES /
+    CUDA_VISIBLE_DEVICES when set.  Falls back to torch.cuda.device_count() where the sysfs tree is absent."""
+    n = None
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(root):
+            with open(os.path.join(root, d, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        n += 1 if int(line.split()[1]) > 0 else 0
+                        break
+    except OSError:
+        n = None
+    if n is None:
+        return torch.cuda.device_count()
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_plan(gpus, argv, env, device_count):
     """engine/launch.py:27-82 for the bench: WHO runs the ranks.
 
     Returns ("run", None) when this process is itself a rank (or the single-GPU run), ("spawn", cmd) when it has to start
-    ``torch.distributed.run`` with one child per GPU -- decided BEFORE anything touches the GPU, so the parent never holds
-    a HIP context -- and raises SystemExit with a message when the request cannot be met (fewer devices than --gpus, or a
+    ``torch.distributed.run`` with one child per GPU -- decided BEFORE anything touches the GPU: ``device_count`` comes from
+    ``visible_gpu_count`` (sysfs, not the HIP runtime), so the parent never holds a device; a rank whose device does not exist
+    fails at ``set_device`` -- and raises SystemExit with a message when the request cannot be met (fewer devices than --gpus, or a
     launcher-provided WORLD_SIZE that contradicts --gpus).  Pure function of its arguments (tests/test_cabi_host.py)."""
     gpus = max(int(gpus), 1)
     if "RANK" in env:
@@ -128,7 +154,7 @@ def main():
     args = ap.parse_args()
 
     # one process per GPU: with --gpus N > 1 and no launcher around us, start N ranks as children (before any GPU call)
-    mode, cmd = launch_plan(args.gpus, sys.argv[1:], os.environ, torch.cuda.device_count())
+    mode, cmd = launch_plan(args.gpus, sys.argv[1:], os.environ, visible_gpu_count() if args.gpus > 1 and "RANK" not in os.environ else 1)
     if mode == "spawn":
         sys.exit(subprocess.call(cmd))
 
