@@ -383,7 +383,11 @@ def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None
     check(st, "cddmsl_conv_wgrad")
     PROFILE.end(e0, _CONV_KERNEL.get(_L().cddmsl_last_kernel(), "conv_wgrad") if e0 is not None else "conv_wgrad",
                 2.0 * (dy.numel() // Cout) * Cout * KH * KW * Cin,
-                (dy.numel() // Cout, Cout, KH * KW * Cin, KH, int(pool), stride))
+                (dy.numel() // Cout, Cout, KH * KW * Cin, KH, int(pool), stride),
+                # algorithmic HBM bytes: both operands once (a long reduction into a small dW is bound by reading them, not by the MFMAs)
+                nbytes=float(_conv_input_pixels(N, H, W, (H // 2) if pool else (H + 2 * pad - KH) // stride + 1,
+                                                 (W // 2) if pool else (W + 2 * pad - KW) // stride + 1, KH, KW, stride, bool(pool)) * Cin * x.element_size()
+                             + dy.numel() * dy.element_size() + out.numel() * 4))
     return out
 
 

@@ -72,7 +72,8 @@ def test_device_batches_stage_through_one_pinned_copy(tmp_path):
         next(it)
 
 
-def test_multi_scale_training_on_the_real_loader_keeps_the_allocator_flat(tmp_path):
+@pytest.mark.parametrize("workers", [0, 2])
+def test_multi_scale_training_on_the_real_loader_keeps_the_allocator_flat(tmp_path, workers):
     """SURVEY.md 8(f)2 / data/build.py:262-308: the paired VOC loader with INPUT.MIN_SIZE_TRAIN multi-scale sampling feeds the
     full step (all three branches) for 24 iterations -- every batch another shape through the kernel dispatch, the workspace
     registry and the gradient buckets -- without an error, with finite losses, and without the caching allocator growing after
@@ -91,7 +92,7 @@ def test_multi_scale_training_on_the_real_loader_keeps_the_allocator_flat(tmp_pa
     tr.model.load_state_dict(synthetic.make_state_dict(0), strict=False)
     tr.clipcap_model.load_state_dict(synthetic.make_mapper_state_dict(1))
     tr.iter, tr.metrics_period = 20000, 1
-    tr.data_loader = data.build_detection_train_loader(cfg, dicts, 4, 0, 1, "cuda:0", num_workers=0)
+    tr.data_loader = data.build_detection_train_loader(cfg, dicts, 4, 0, 1, "cuda:0", num_workers=workers)   # (2: spawned worker processes)
     tr._data_loader_iter = iter(tr.data_loader)
     shapes, reserved = set(), []
     for it in range(24):
