@@ -242,6 +242,81 @@ __global__ __launch_bounds__(256) void k_probe_pipe(const u32x4* src, float* sin
   if (t == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// 8 waves of 128 x 64 (two per SIMD), each software-pipelined the same way: 6 fragment reads of k-step s+1 under the 8 MFMAs of k-step s,
+// 2 LDS-DMA instructions per wave and k-step for the staging (STAGE == 2)
+template <int STAGE>
+__global__ __launch_bounds__(512) void k_probe_pipe8(const u32x4* src, float* sink, unsigned long long* stamps, int iters) {
+  __shared__ u32x4 lds[8192];
+  const int t = threadIdx.x, lane = t & 63;
+  for (int i = t; i < 4096; i += blockDim.x) lds[i] = src[(blockIdx.x * 4096 + i) & 0xfffff];
+  __syncthreads();
+  f32x16 acc[8];
+  for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  u32x4 fa[2][4], fb[2][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) fa[0][a] = lds[(lane + 64 * a) & 4095];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) fb[0][b] = lds[(lane + 64 * b + 2048) & 4095];
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                           // four k-steps = 32 MFMAs per iteration
+      const int cur = ks & 1, nxt = cur ^ 1;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[nxt][a] = lds[(lane + 64 * a + 256 * ((it + ks + 1) & 7)) & 4095];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[nxt][b] = lds[(lane + 64 * b + 2048 + 256 * ((it + ks + 1) & 7)) & 4095];
+      if (STAGE == 2) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((blockIdx.x * 4096 + t + 512 * w + 1024 * ((it + ks) & 3)) & 0xfffff)),
+                                           (__attribute__((address_space(3))) void*)&lds[4096 + (t & ~63) + 512 * w + 1024 * ((it + ks) & 3)], 16, 0, 0);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a * 2 + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][a]), __builtin_bit_cast(bf16x8, fb[cur][b]), acc[a * 2 + b], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+      }
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+  for (int a = 0; a < 8; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+  if (s == 12345.678f) sink[0] = s + lds[4096 + t][0];
+  if (t == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <int STAGE> static void run_pipe8(const char* what, const u32x4* src, float* sink, unsigned long long* stamps, int nblk) {
+  const int iters = 4000, threads = 512;
+  auto t0 = std::chrono::steady_clock::now();
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.0) {
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_probe_pipe8<STAGE>), dim3(nblk), dim3(threads), 0, 0, src, sink, stamps, iters);
+    hipDeviceSynchronize();
+  }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((k_probe_pipe8<STAGE>), dim3(nblk), dim3(threads), 0, 0, src, sink, stamps, iters);
+  hipEventRecord(e1);
+  hipDeviceSynchronize();
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(2 * nblk);
+  hipMemcpy(h.data(), stamps, sizeof(unsigned long long) * 2 * nblk, hipMemcpyDeviceToHost);
+  std::vector<double> ghz;
+  for (int b = 0; b < nblk; ++b) ghz.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1);
+  std::sort(ghz.begin(), ghz.end());
+  const double flops = (double)nblk * (threads / 64) * iters * 32.0 * 2.0 * 32 * 32 * 16;
+  const double clk = ghz[ghz.size() / 2];
+  printf("%-64s waves/SIMD %d  clock %.3f GHz  %.1f TFLOP/s  = %.3f of the clock's MFMA peak (%.0f TF)\n",
+         what, threads / 256, clk, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / (clk * 1e9 * 1024 * 1024.0), clk * 1024 * 1024.0 / 1e3);
+}
+
 template <int STAGE> static void run_pipe(const char* what, const u32x4* src, float* sink, unsigned long long* stamps, int nblk) {
   const int iters = 4000, threads = 256;
   auto t0 = std::chrono::steady_clock::now();
@@ -347,6 +422,8 @@ int main() {
   run_pipe<0>("4 waves of 128 x 128, reads of step s+1 under the MFMAs of step s", src, sink, stamps, nblk);
   run_pipe<1>("4 waves of 128 x 128, pipelined reads + 0.25 KB staging writes", src, sink, stamps, nblk);
   run_pipe<2>("4 waves of 128 x 128, pipelined reads + 0.25 KB staged by LDS-DMA", src, sink, stamps, nblk);
+  run_pipe8<0>("8 waves of 128 x 64, reads of step s+1 under the MFMAs of step s", src, sink, stamps, nblk);
+  run_pipe8<2>("8 waves of 128 x 64, pipelined reads + 0.25 KB staged by LDS-DMA", src, sink, stamps, nblk);
   run_bl2<1>("8 waves, A from LDS (0.5 + 0.125 KB), B from L2, 1 group ahead", src, sink, stamps, nblk);
   run_bl2<2>("8 waves, A from LDS (0.5 + 0.125 KB), B from L2, 2 groups ahead", src, sink, stamps, nblk);
   return 0;
