@@ -1668,6 +1668,207 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp8 configuration (BASELINE.json configs[4]): the weight gradient of a "same" convolution on the e4m3 copies of BOTH operands
+// (the activation's copy its producer wrote for the forward convolution, the output gradient's copy made for the input-gradient
+// convolution), v_mfma_scale_f32_32x32x64_f8f6f4.  Output tile 256 n x 256 k, 8 waves of 128 n x 64 k as in k_wgrad256 (same
+// accumulator layout: the same epilogue and k_wgrad_reduce).  Reduction tiles of 64 pixels = ONE MFMA step: an image is
+// [64 pixels][256 channels] bytes, 16 KiB, 16-byte chunk c of row r stored at chunk c ^ ((r & 7) << 1); fragments are read with
+// ds_read_b64_tr_b8 (tools/tr_b8_probe.hip: per 16 lanes a block of 8 rows x 16 columns of bytes, lane 2q+p supplies row q columns
+// 8p.., lane i receives column i) -- lane half h takes pixels 32h..32h+31 of the tile in 4 reads, for both operands alike, which is
+// all a dot product needs; a 32-lane half touches 8 rows x 32 contiguous bytes whose chunk pairs the XOR spreads over all 64 banks.
+// Loop: a ring of 4 LDS buffers filled by LDS-DMA two tiles ahead (counted vmcnt), ONE barrier per tile, the 24 fragment reads of
+// tile t+1 issued between the 8 MFMAs of tile t into a second register set.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_wgrad256_f8(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds[4 * 2 * 64 * 16];   // byte = ring<<15 | ab<<14 | row*256 + slot*16
+  const int t = threadIdx.x, lane = t & 63;
+  const int wvu = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = wvu >> 2, wk = wvu & 3;
+  const int ntn = p.Cout >> 8, ntk = p.K >> 8;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_k = bid % ntk; bid /= ntk;
+  const int tile_n = bid % ntn; bid /= ntn;
+  const int n0 = tile_n * 256, k0 = tile_k * 256;
+  const int mt0 = bid * p.mtiles_per_split;
+  const int nmt_real = min(p.mtiles_per_split, (p.M + WM - 1) / WM - mt0);
+  const int nmt = (nmt_real + 1) & ~1;                        // an even number of tiles (one straight-line loop body of two): the extra one is all zeros
+  const int mlim = min(p.M, (mt0 + nmt_real) * WM);           // rows at or past this are not this block's
+  const bool taps = !(p.KH == 1 && p.KW == 1);
+
+  // ---- staging: wave instruction i of a thread fills rows (i*8 + wave)*4 .. +3 of an image, lane -> (row lane>>4, slot lane&15)
+  const int rq = lane >> 4, r8 = (wvu & 1) * 4 + rq;
+  const int cl = (lane & 15) ^ (r8 << 1);                      // logical chunk of this lane's slot
+  const int pp = k0 / p.Cin, coff = (k0 - pp * p.Cin) >> 4;    // the tile's filter tap and first chunk within the pixel (256 | Cin)
+  const int ky = pp / p.KW, kx = pp - ky * p.KW;
+  unsigned vd[2], vx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = i * 32 + wvu * 4 + rq;
+    vd[i] = (unsigned)(row * p.ldd + cl * 16);
+    vx[i] = (unsigned)(((row + ky * p.Wi + kx) * p.xrs + coff + cl) * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + ((long)mt0 * WM * p.ldd + n0)), 0, 0x80000000u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + ((long)mt0 * WM - p.pad * p.Wi - p.pad) * p.xrs * 16), 0, 0x80000000u, 0x00020000);
+  const unsigned dstep = (unsigned)(WM * p.ldd), xstep = (unsigned)(WM * p.xrs * 16);
+  const int mrow = mt0 * WM + wvu * 4 + rq;                    // + T*64 + i*32
+  char* const L = (char*)lds;
+  auto stage = [&](int T) {
+    char* dst = L + ((T & 3) << 15) + wvu * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mrow + T * WM + i * 32;
+      bool ok = m < mlim;
+      const unsigned dinv = ok ? 0u : 0x80000000u;
+      if (taps) {
+        const unsigned mm = min((unsigned)m, (unsigned)(p.M - 1));
+        const unsigned tq = fdiv(mm, p.dWo);
+        const unsigned ox = mm - tq * p.Wo;
+        const unsigned oy = tq - fdiv(tq, p.dHo) * p.Ho;
+        ok = ok & ((unsigned)((int)oy - p.pad + ky) < (unsigned)p.Hi) & ((unsigned)((int)ox - p.pad + kx) < (unsigned)p.Wi);
+      }
+      const unsigned xinv = ok ? 0u : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(dst + i * 8192), 16,
+                                               (int)(vd[i] | dinv), (int)(T * dstep), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + (1 << 14) + i * 8192), 16,
+                                               (int)(vx[i] | xinv), (int)(T * xstep), 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- transposed fragment reads: per-lane byte addresses of read 0 in ring buffer 0 (+ 2048 per read: immediate)
+  const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)L;
+  unsigned adA[4], adB[2];
+  {
+    const int q = (lane & 15) >> 1, gb = (lane >> 4) & 1;
+    const unsigned rowb = (unsigned)((32 * (lane >> 5) + q) * 256 + 8 * (lane & 1));
+#pragma unroll
+    for (int a = 0; a < 4; ++a) adA[a] = lbase + rowb + (unsigned)((((wn * 8 + a * 2 + gb) ^ (q << 1)) & 15) << 4);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) adB[b] = lbase + (1u << 14) + rowb + (unsigned)((((wk * 4 + b * 2 + gb) ^ (q << 1)) & 15) << 4);
+  }
+  // Register plan (accumulators 128): dY fragments ONE set of 4 (32 registers), X fragments two sets of 2 (32).  A tile's 8 MFMAs run as
+  // two groups: G0 = dY fragments 0,1 (while fragments 2,3 of the same tile are read), G1 = fragments 2,3 (while fragments 0,1 and the
+  // X fragments of the NEXT tile are read into the registers G0 has released / the other X set).
+  u32x2 fa[4][4], fb[2][2][4];                                 // [fragment][read], [register set][fragment][read]
+#define CDDMSL_TR8(DST, AD, R) asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(DST) : "v"(AD), "i"((R) * 2048));
+#define CDDMSL_TR8x4(F, AD) CDDMSL_TR8(F[0], AD, 0) CDDMSL_TR8(F[1], AD, 1) CDDMSL_TR8(F[2], AD, 2) CDDMSL_TR8(F[3], AD, 3)
+// the waits name the registers the retired reads wrote: no MFMA that consumes them (and no copy of them) can be placed above
+#define CDDMSL_F8_WAIT_TOP(S)                                                                                                    \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]),                          \
+               "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]),                                                   \
+               "+v"(fb[S][0][0]), "+v"(fb[S][0][1]), "+v"(fb[S][0][2]), "+v"(fb[S][0][3]),                                       \
+               "+v"(fb[S][1][0]), "+v"(fb[S][1][1]), "+v"(fb[S][1][2]), "+v"(fb[S][1][3]) :: "memory");
+#define CDDMSL_F8_WAIT_MID()                                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[2][2]), "+v"(fa[2][3]),                          \
+               "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fa[3][2]), "+v"(fa[3][3]) :: "memory");
+  auto mma = [&](auto SC, auto AC, auto BC) {
+    constexpr int S = decltype(SC)::value, a = decltype(AC)::value, b = decltype(BC)::value;
+    const i32x8 va = {(int)fa[a][0][0], (int)fa[a][0][1], (int)fa[a][1][0], (int)fa[a][1][1],
+                      (int)fa[a][2][0], (int)fa[a][2][1], (int)fa[a][3][0], (int)fa[a][3][1]};
+    const i32x8 vb = {(int)fb[S][b][0][0], (int)fb[S][b][0][1], (int)fb[S][b][1][0], (int)fb[S][b][1][1],
+                      (int)fb[S][b][2][0], (int)fb[S][b][2][1], (int)fb[S][b][3][0], (int)fb[S][b][3][1]};
+    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc[a][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    // an MFMA is a register-only instruction: free to sink below later reads, waits and barriers (it did: all 8 of a tile ended up
+    // behind the NEXT tile's barrier).  The empty volatile statement names its result, which orders it among the volatile reads / waits.
+    asm volatile("" : "+v"(acc[a][b]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  auto body = [&](int kt, auto SC) {
+    constexpr int S = decltype(SC)::value, N = S ^ 1;
+    using IS = std::integral_constant<int, S>;
+    if (kt + 1 < nmt) {                                        // this thread's part of tile kt+1 has landed (tile kt+2 may be in flight)
+      if (kt + 2 < nmt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                              // ... and everyone's; every wave is past its reads of tile kt-1
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 3 < nmt) stage(kt + 3);                           // into the buffer tile kt-1 occupied
+    CDDMSL_F8_WAIT_TOP(S)
+    __builtin_amdgcn_sched_barrier(0);
+    {                                                          // G0, reading dY fragments 2, 3 of this tile
+      const unsigned ro = (unsigned)(kt & 3) << 15;
+      const unsigned a2 = adA[2] + ro, a3 = adA[3] + ro;
+      CDDMSL_TR8x4(fa[2], a2)
+      mma(IS{}, I0{}, I0{}); mma(IS{}, I0{}, I1{});
+      CDDMSL_TR8x4(fa[3], a3)
+      mma(IS{}, I1{}, I0{}); mma(IS{}, I1{}, I1{});
+    }
+    CDDMSL_F8_WAIT_MID()
+    __builtin_amdgcn_sched_barrier(0);
+    {                                                          // G1, reading the next tile's dY fragments 0, 1 and X fragments
+      // (behind the last tile: a buffer of the ring that holds an older tile -- read and never used)
+      const unsigned ro = (unsigned)((kt + 1) & 3) << 15;
+      const unsigned a0 = adA[0] + ro, a1 = adA[1] + ro, b0 = adB[0] + ro, b1 = adB[1] + ro;
+      CDDMSL_TR8x4(fa[0], a0)
+      mma(IS{}, I2{}, I0{});
+      CDDMSL_TR8x4(fa[1], a1)
+      mma(IS{}, I2{}, I1{});
+      CDDMSL_TR8x4(fb[N][0], b0)
+      mma(IS{}, I3{}, I0{});
+      CDDMSL_TR8x4(fb[N][1], b1)
+      mma(IS{}, I3{}, I1{});
+    }
+  };
+  if (nmt > 0) {
+    stage(0);
+    if (nmt > 1) stage(1);
+    if (nmt > 2) stage(2);
+    if (nmt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nmt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    CDDMSL_TR8x4(fa[0], adA[0]) CDDMSL_TR8x4(fa[1], adA[1]) CDDMSL_TR8x4(fb[0][0], adB[0]) CDDMSL_TR8x4(fb[0][1], adB[1])
+    for (int kt = 0; kt < nmt; kt += 2) {
+      body(kt, I0{});
+      body(kt + 1, I1{});
+    }
+  }
+#undef CDDMSL_TR8x4
+#undef CDDMSL_F8_WAIT_TOP
+#undef CDDMSL_F8_WAIT_MID
+#undef CDDMSL_TR8
+
+  const int r = lane & 31, h = lane >> 5;
+  if (p.ws) {          // split reduction through the workspace, accumulators in fragment order (k_wgrad256's layout: k_wgrad_reduce<8, 32>)
+    f32x4* dst = (f32x4*)p.ws + ((long)(bid * ntn + tile_n) * ntk + tile_k) * (8 * 32 * 64) + (wvu * 32) * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 v = {acc[a][b][4 * g4], acc[a][b][4 * g4 + 1], acc[a][b][4 * g4 + 2], acc[a][b][4 * g4 + 3]};
+          dst[((a * 2 + b) * 4 + g4) * 64] = v;
+        }
+  } else
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int k = k0 + wk * 64 + b * 32 + r;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int n = n0 + wn * 128 + a * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        atomicAdd(p.dw + (long)n * p.ldo + k, acc[a][b][g] * (p.scale ? p.scale[n] : 1.f));
+      }
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void weight_prep_body(const float* w, const float* scale, char* wf, char* wd, int Cout, int KH, int KW, int Cin,
                                                  long first, long stride) {
@@ -3080,6 +3281,57 @@ extern "C" int cddmsl_conv_wgrad(const void* x, const void* dy, float* dw, const
     if (dtype == 0) hipLaunchKernelGGL(k_conv_wgrad<__bf16>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_conv_wgrad<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
   }
+  return launch_status();
+}
+
+// fp8 configuration: dW[Cout][KH*KW*Cin] (f32) += scale[n] * sum_m dy8[m][n] * im2col(x8)[m][k], both operands OCP e4m3 bytes (NHWC, dy
+// rows ldd bytes apart); ``scale`` must carry the two dequantisation factors (x the FrozenBN scale).  "Same" convolutions only
+// (stride 1, 2 * pad == KH - 1), Cout, Cin multiples of 256.  cddmsl_conv_wgrad_fp8_ok tells whether a shape is taken.
+extern "C" int cddmsl_conv_wgrad_fp8_ok(int Cin, int Cout, int KH, int KW, int pad, int ldd) {
+  return (Cin % 256 == 0 && Cout % 256 == 0 && KH == KW && (KH & 1) && 2 * pad == KH - 1 && ldd % 16 == 0) ? 1 : 0;
+}
+extern "C" int cddmsl_conv_wgrad_fp8(const void* x8, const void* dy8, float* dw, const float* scale, int Nimg, int Hi, int Wi, int Cin,
+                                     int Cout, int KH, int KW, int pad, int ldd, void* stream) {
+  if (Nimg < 0 || Hi <= 0 || Wi <= 0 || !cddmsl_conv_wgrad_fp8_ok(Cin, Cout, KH, KW, pad, ldd) || ldd < Cout) return CDDMSL_ERR_ARG;
+  WgradArgs a;
+  a.x = (const char*)x8; a.dy = (const char*)dy8; a.dw = dw; a.scale = scale;
+  a.Nimg = Nimg; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = 1; a.pad = pad;
+  a.ldd = ldd; a.pool = 0; a.Ho = Hi; a.Wo = Wi;
+  const long M = (long)Nimg * Hi * Wi;
+  if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
+  a.M = (int)M; a.cpp = Cin / 16; a.Kc = KH * KW * a.cpp; a.K = KH * KW * Cin; a.ncc = Cout / 16;
+  a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
+  a.xrs = a.cpp; a.ldo = a.K; a.direct = 0; a.bx = a.bd = a.bo = 0;
+  if (a.M == 0) return CDDMSL_OK;
+  const int total_mt = (a.M + WM - 1) / WM;
+  // one block per CU: the split count whose grid fills its last 256-block round best, at least 16 reduction tiles per block
+  const long tiles = (long)(Cout / 256) * (a.K / 256), maxs = (total_mt + 15) / 16;
+  long sp = 1;
+  double best = -1.0;
+  for (int r = 1; r <= 6; ++r) {
+    long c = (256L * r) / tiles;
+    if (c < 1) continue;
+    if (c > maxs) c = maxs;
+    const long blocks = tiles * c, rounds = (blocks + 255) / 256;
+    const double eff = (double)blocks / (256.0 * rounds);
+    if (eff > best + 0.02) { best = eff; sp = c; }
+    if (c == maxs) break;
+  }
+  a.mtiles_per_split = (int)((total_mt + sp - 1) / sp);
+  sp = (total_mt + a.mtiles_per_split - 1) / a.mtiles_per_split;
+  // buffer addressing: lane offset + soffset stay below 2 GiB inside one block's reduction range
+  const long rowb = ldd > a.xrs * 16 ? ldd : a.xrs * 16;
+  if (((long)a.mtiles_per_split * WM + WM + 2L * Wi + 2) * rowb + (1L << 20) >= (1L << 31)) return CDDMSL_ERR_ARG;
+  g_last_kernel = 12;
+  if (g_plan_only) return CDDMSL_OK;
+  if (sp > 1 && use_workspace(tiles * sp, 65536)) {
+    a.ws = (float*)g_ws;
+    hipLaunchKernelGGL(k_wgrad256_f8, dim3((unsigned)(tiles * sp)), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_wgrad_reduce<8, 32>), dim3((unsigned)(tiles * 64)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)g_ws, dw, scale,
+                       Cout / 256, a.K / 256, (int)sp, Cout, a.K, a.ldo);
+    return launch_status();
+  }
+  hipLaunchKernelGGL(k_wgrad256_f8, dim3((unsigned)(tiles * sp)), dim3(512), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

@@ -155,7 +155,7 @@ class _Profiler:
 
 PROFILE = _Profiler()
 # cddmsl_last_kernel() ids -> profiler row names (one row per KERNEL, so the roofline object describes one kernel)
-_CONV_KERNEL = {10: "k_conv_fwd256_fp8", 11: "k_conv_fwd2", 1: "k_conv_fwd", 2: "k_conv_fwd_reg", 3: "k_conv_fwd256", 4: "k_conv_wgrad", 5: "k_conv_wgrad_dma", 6: "k_wgrad256", 7: "k_gemm_tn_stream", 8: "k_conv3x3_small", 9: "k_gemm_tn_small"}
+_CONV_KERNEL = {10: "k_conv_fwd256_fp8", 11: "k_conv_fwd2", 1: "k_conv_fwd", 2: "k_conv_fwd_reg", 3: "k_conv_fwd256", 4: "k_conv_wgrad", 5: "k_conv_wgrad_dma", 6: "k_wgrad256", 7: "k_gemm_tn_stream", 8: "k_conv3x3_small", 9: "k_gemm_tn_small", 12: "k_wgrad256_fp8"}
 
 
 def _timed(name):
@@ -388,6 +388,37 @@ def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None
                 nbytes=float(_conv_input_pixels(N, H, W, (H // 2) if pool else (H + 2 * pad - KH) // stride + 1,
                                                  (W // 2) if pool else (W + 2 * pad - KW) // stride + 1, KH, KW, stride, bool(pool)) * Cin * x.element_size()
                              + dy.numel() * dy.element_size() + out.numel() * 4))
+    return out
+
+
+def conv_wgrad_fp8_ok(M, Cin, Cout, KH, KW, pad):
+    """shapes the e4m3 weight-gradient kernel takes AND wins on: whole 256 x 256 output tiles of a "same" convolution with taps (a
+    1x1 layer's weight gradient is bound by reading its operands once, which the bf16 kernel does at the same rate per byte only for
+    twice the bytes -- the copies it would need are not all there) and a reduction long enough to fill the chip"""
+    min_m = int(os.environ.get("CDDMSL_FP8_WGRAD_MIN_M", "300000"))     # (the RoI head's 3x3 layers; tests lower it to reach the kernel at small sizes)
+    return os.environ.get("CDDMSL_FP8_WGRAD", "1") != "0" and KH * KW > 1 and M >= min_m \
+        and bool(_L().cddmsl_conv_wgrad_fp8_ok(Cin, Cout, KH, KW, pad, Cout))
+
+
+def conv_wgrad_fp8(x8, dy8, w_shape, scale, pad=0, out=None):
+    """dW[Cout,KH,KW,Cin] (f32) += scale[n] * sum_m dy8[m,n] * im2col(x8)[m,k]; x8, dy8 uint8 (e4m3) NHWC, stride 1, "same" padding.
+    ``scale`` must carry the two dequantisation factors (x the FrozenBN scale)."""
+    require_cuda(x8, dy8, scale, out)
+    Cout, KH, KW, Cin = w_shape
+    N, H, W, Cin2 = x8.shape
+    assert Cin == Cin2 and x8.dtype == torch.uint8 and dy8.dtype == torch.uint8 and x8.is_contiguous() and dy8.is_contiguous()
+    assert dy8.shape[-1] == Cout and dy8.numel() // Cout == N * H * W and 2 * pad == KH - 1
+    assert scale is not None and scale.dtype == torch.float32 and scale.numel() == Cout and scale.is_contiguous()
+    if out is None:
+        out = torch.zeros(w_shape, device=x8.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == tuple(w_shape)
+    ensure_workspace(x8.device)
+    def launch():
+        return _L().cddmsl_conv_wgrad_fp8(ptr(x8), ptr(dy8), ptr(out), ptr(scale), N, H, W, Cin, Cout, KH, KW, pad, Cout, stream_ptr())
+    e0 = PROFILE.begin(name="k_wgrad256_fp8") if PROFILE.on else None
+    check(launch(), "cddmsl_conv_wgrad_fp8")
+    PROFILE.end(e0, "k_wgrad256_fp8", 2.0 * (N * H * W) * Cout * KH * KW * Cin, (N * H * W, Cout, KH * KW * Cin, KH, 0, 1),
+                nbytes=float(x8.numel() + dy8.numel() + out.numel() * 4))
     return out
 
 

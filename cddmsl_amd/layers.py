@@ -237,6 +237,40 @@ def fp8_emit_for(consumer_pw, out_shape, pad, fp8, producer_cout=None, producer_
     return fp8_act_slot(consumer_pw).emit()
 
 
+def fp8_copy(t, slot):
+    """the e4m3 copy of ``t`` under ``slot``'s scale: the one its producer wrote (``t._fp8``), else one quantisation pass -- whose
+    result stays attached to ``t`` for the tensor's other consumers (a gradient feeds an input-gradient AND a weight-gradient GEMM)"""
+    made = getattr(t, "_fp8", None)
+    if made is not None and made[1] == slot.scale.data_ptr():
+        return made[0]
+    slot.calibrate(t)
+    t8 = hip.quantize_fp8(t, slot.scale, slot.amax)
+    t._fp8 = (t8, slot.scale.data_ptr())
+    return t8
+
+
+def wgrad_auto(x, dy, pw, scale, pad, out, fp8=False, x8=None, dy_slot=None):
+    """Weight gradient of a stride-1 convolution: ``hip.conv_wgrad`` on the bf16 / f32 tensors, or -- fp8 configuration, shapes
+    ``hip.conv_wgrad_fp8_ok`` takes -- the e4m3 kernel on the activation's copy kept from the forward pass (``x8``, made under
+    ``fp8_act_slot(pw)``) and the gradient's copy under ``dy_slot`` (the one its input-gradient convolution reads); both
+    dequantisation factors ride in the per-channel scale."""
+    Cout, KH, KW, Cin = _ohwi(pw.param).shape
+    if fp8 and x8 is not None and dy_slot is not None and dy.dtype == torch.bfloat16 \
+            and hip.conv_wgrad_fp8_ok(dy.numel() // Cout, Cin, Cout, KH, KW, pad):
+        d8 = fp8_copy(dy, dy_slot)
+        deq = fp8_act_slot(pw).deq * dy_slot.deq
+        eff = deq * scale if scale is not None else deq.expand(Cout).contiguous()
+        return hip.conv_wgrad_fp8(x8, d8, (Cout, KH, KW, Cin), eff, pad=pad, out=out)
+    return hip.conv_wgrad(x, dy, (Cout, KH, KW, Cin), scale, pad=pad, out=out)
+
+
+def _fp8_made_for(t, pw):
+    """the e4m3 copy of ``t`` made under the activation slot of ``pw``'s convolution (by its producer or by ``conv_fwd_auto``), or None"""
+    made = getattr(t, "_fp8", None)
+    sl = getattr(pw, "_fp8_slot", None)
+    return made[0] if made is not None and sl is not None and made[1] == sl.scale.data_ptr() else None
+
+
 def conv_fwd_auto(x, pw, scale=None, bias=None, fp8=False, emit8=None, **kw):
     """``hip.conv_fwd`` on the prepared bf16 / f32 weights, or -- with ``fp8`` on shapes the e4m3 kernel takes and wins on
     (``hip.conv_fwd_fp8_ok``: MFMA-bound in bf16) -- the e4m3 kernel on the input's e4m3 copy: the one its producer wrote
@@ -249,12 +283,7 @@ def conv_fwd_auto(x, pw, scale=None, bias=None, fp8=False, emit8=None, **kw):
         pad = kw.get("pad", 0)
         if _fp8_eligible(pw, x.shape, pad):
             sl = fp8_act_slot(pw)
-            made = getattr(x, "_fp8", None)
-            if made is not None and made[1] == sl.scale.data_ptr():
-                x8 = made[0]
-            else:
-                sl.calibrate(x)
-                x8 = hip.quantize_fp8(x, sl.scale, sl.amax)
+            x8 = fp8_copy(x, sl)
             w8, d_w = fp8_weight(pw)
             eff = (sl.deq * d_w) * scale if scale is not None else (sl.deq * d_w).expand(Cout).contiguous()
             return hip.conv_fwd_fp8(x8, w8, eff, bias, kw.get("residual"), kw.get("relu", False), kw.get("relu_mask"), pad, emit8=emit8)
@@ -304,12 +333,7 @@ def dgrad_auto(g, pw, fp8=False, slot=None, emit8=None, **kw):
         N, H, W, _ = g.shape
         M = N * (H + 2 * pad - KH + 1) * (W + 2 * pad - KW + 1)
         if hip.conv_fwd_fp8_ok(M, Cin_d, Cout_d, KH, KW, pad):
-            made = getattr(g, "_fp8", None)
-            if made is not None and made[1] == slot.scale.data_ptr():
-                g8 = made[0]
-            else:
-                slot.calibrate(g)
-                g8 = hip.quantize_fp8(g, slot.scale, slot.amax)
+            g8 = fp8_copy(g, slot)
             wd8, d_w = fp8_weight_d(pw, wd)
             return hip.conv_fwd_fp8(g8, wd8, (slot.deq * d_w).expand(Cout_d).contiguous(), None, kw.get("residual"), False, kw.get("relu_mask"),
                                     pad, emit8=emit8)
@@ -520,10 +544,10 @@ def _block_forward(x, bp, save, px_given=None, next_pw=None, out_spec=None):
         idn = x
     out_shape = (p2.shape[0], p2.shape[1], p2.shape[2], _ohwi(bp.w[2]).shape[0])
     out = conv_fwd_auto(p2, bp.pw[2], s3, b3, f8, emit8=fp8_emit_for(next_pw, out_shape, 0, f8), residual=idn, relu=True, out_spec=out_spec)
-    return out, ((o1, o2, p2 if pool else None, px if pool else None) if save else None)
+    return out, ((o1, o2, p2 if pool else None, px if pool else None, _fp8_made_for(o1, bp.pw[1]) if f8 else None) if save else None)
 
 
-def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None):
+def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None, o1_8=None):
     """gs = dL/d(pre-ReLU sum) of this block (already masked by out>0).  Returns dL/dx, masked by x>0 when
     ``mask_x`` (x is the previous block's post-ReLU output) so it is directly the previous block's ``gs``.
     fp8 configuration: the input-gradient convolutions with a long reduction (conv3's, conv2's, the downsample conv's) run on
@@ -544,8 +568,9 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None):
     else:
         e8 = d2_slot.emit() if f8 and _fp8_dgrad_wanted(bp.pw[1], o2.shape, 1, f8) else None
         dpre2 = dgrad_auto(gs, bp.pw[2], f8, gs_slot, emit8=e8, relu_mask=o2)
-    hip.conv_wgrad(o1, dpre2, shp(w2p), s2, pad=1, out=_ohwi(_grad_buf(w2p)))
+    # (conv2's input gradient first: it leaves the e4m3 copy of dpre2 attached, which the fp8 weight gradient reads as well)
     dpre1 = dgrad_auto(dpre2, bp.pw[1], f8, d2_slot, pad=1, relu_mask=o1)
+    wgrad_auto(o1, dpre2, bp.pw[1], s2, 1, _ohwi(_grad_buf(w2p)), f8, o1_8, d2_slot)
     hip.conv_wgrad(x, dpre1, shp(w1p), s1, out=_ohwi(_grad_buf(w1p)))
     if wdp is not None:
         hip.conv_wgrad(px if pool else x, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
@@ -572,26 +597,28 @@ class ResStageFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, blocks, out_grad_premasked=False, px0=None, out_spec=None):
         ctx.out_grad_premasked = out_grad_premasked
-        saved = [x]
+        saved, o1_8s = [x], []
         cur = x
         for bi, bp in enumerate(blocks):
             cur, mids = _block_forward(cur, bp, True, px0 if bi == 0 else None, blocks[bi + 1].pw[0] if bi + 1 < len(blocks) else None,
                                        out_spec if bi + 1 == len(blocks) else None)
             saved += [mids[0], mids[1], mids[2], mids[3], cur]
+            o1_8s.append(mids[4])
         ctx.blocks = blocks
-        ctx.save_for_backward(*saved)
+        ctx.save_for_backward(*saved, *o1_8s)         # (fp8 configuration: conv2's e4m3 input copies, for its weight gradient)
         return cur
 
     @staticmethod
     def backward(ctx, g):
-        saved = ctx.saved_tensors
         blocks = ctx.blocks
+        saved, o1_8s = ctx.saved_tensors[:-len(blocks)], ctx.saved_tensors[-len(blocks):]
         need_dx = ctx.needs_input_grad[0]
         # mask by the stage output's ReLU -- unless the one consumer of the output has done it (res_stage_attnpool)
         gs = g.contiguous() if ctx.out_grad_premasked else hip.relu_bwd(g.contiguous(), saved[-1])
         for i in range(len(blocks) - 1, -1, -1):
             x, o1, o2, p2, px = saved[5 * i: 5 * i + 5]
-            gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0, prev_bp=blocks[i - 1] if i > 0 else None)
+            gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0, prev_bp=blocks[i - 1] if i > 0 else None,
+                                 o1_8=o1_8s[i])
         return gs, None, None, None, None, None
 
 
@@ -648,7 +675,7 @@ def _roi_block0_forward(feat, rois, bp, out_size, scale, sr, extra, next_pw=None
         avgpool2(roi_align(x))  (-> downsample conv)  written directly, pooled           rows instead of 1.6 M crop rows at 8192 RoIs)
 
     The [K,14,14,1024] crop tensor (3.3 GB) is never written or read; the 512-channel o1 (half of it) is what conv2 needs
-    anyway.  Returns (o1, o2, p2, px, out)."""
+    anyway.  Returns (o1, o2, p2, px, out, e4m3 copy of o1 or None)."""
     T = feat.dtype
     (s1, b1), (s2, b2), (s3, b3), bnd = bp.bn
     w1, _ = bp.pw[0].get(T, False)
@@ -667,7 +694,7 @@ def _roi_block0_forward(feat, rois, bp, out_size, scale, sr, extra, next_pw=None
     idn = conv_fwd_auto(px, bp.pw[3], bnd[0], bnd[1], f8)
     out_shape = (p2.shape[0], p2.shape[1], p2.shape[2], _ohwi(bp.w[2]).shape[0])
     out = conv_fwd_auto(p2, bp.pw[2], s3, b3, f8, emit8=fp8_emit_for(next_pw, out_shape, 0, f8), residual=idn, relu=True)
-    return o1, o2, p2, px, out
+    return o1, o2, p2, px, out, (_fp8_made_for(o1, bp.pw[1]) if f8 else None)
 
 
 class RoIStageFn(torch.autograd.Function):
@@ -680,26 +707,27 @@ class RoIStageFn(torch.autograd.Function):
     def forward(ctx, feat, anchor, rois, roi_start, blocks, out_size, scale, sr, out_grad_premasked, extra):
         feat = feat.contiguous()
         nxt = lambda i: blocks[i + 1].pw[0] if i + 1 < len(blocks) else None
-        o1, o2, p2, px, cur = _roi_block0_forward(feat, rois, blocks[0], out_size, scale, sr, extra, nxt(0))
-        saved = [feat, rois, roi_start, extra, o1, o2, p2, px, cur]
+        o1, o2, p2, px, cur, o1_8 = _roi_block0_forward(feat, rois, blocks[0], out_size, scale, sr, extra, nxt(0))
+        saved, o1_8s = [feat, rois, roi_start, extra, o1, o2, p2, px, cur], [o1_8]
         for bi, bp in enumerate(blocks[1:], start=1):
             cur, mids = _block_forward(cur, bp, True, None, nxt(bi))
             saved += [mids[0], mids[1], mids[2], mids[3], cur]
+            o1_8s.append(mids[4])
         ctx.blocks, ctx.meta = blocks, (out_size, scale, sr, out_grad_premasked)
-        ctx.save_for_backward(*saved)
+        ctx.save_for_backward(*saved, *o1_8s)         # (fp8 configuration: conv2's e4m3 input copies, for its weight gradient)
         return cur
 
     @staticmethod
     def backward(ctx, g):
-        saved = ctx.saved_tensors
         blocks = ctx.blocks
+        saved, o1_8s = ctx.saved_tensors[:-len(blocks)], ctx.saved_tensors[-len(blocks):]
         out_size, scale, sr, premasked = ctx.meta
         feat, rois, roi_start, extra = saved[:4]
         st = saved[4:]                               # per block: o1, o2, p2, px, out
         gs = g.contiguous() if premasked else hip.relu_bwd(g.contiguous(), st[-1])
         for i in range(len(blocks) - 1, 0, -1):
             o1, o2, p2, px = st[5 * i: 5 * i + 4]
-            gs = _block_backward(gs, st[5 * i - 1], o1, o2, p2, px, blocks[i], True, mask_x=True, prev_bp=blocks[i - 1])
+            gs = _block_backward(gs, st[5 * i - 1], o1, o2, p2, px, blocks[i], True, mask_x=True, prev_bp=blocks[i - 1], o1_8=o1_8s[i])
         bp = blocks[0]
         o1, o2, p2, px = st[0:4]
         T = o1.dtype
@@ -712,8 +740,8 @@ class RoIStageFn(torch.autograd.Function):
         d2_slot = fp8_slot_of(bp.pw[1], "_fp8_g") if f8 else None
         hip.conv_wgrad(p2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
         dpre2 = hip.avgpool2_bwd(dgrad_auto(gs, bp.pw[2], f8, gs_slot), tuple(o2.shape), mask=o2)
-        hip.conv_wgrad(o1, dpre2, shp(w2p), s2, pad=1, out=_ohwi(_grad_buf(w2p)))
         dpre1 = dgrad_auto(dpre2, bp.pw[1], f8, d2_slot, pad=1, relu_mask=o1)                # [K+E,14,14,planes] wrt bn1's output
+        wgrad_auto(o1, dpre2, bp.pw[1], s2, 1, _ohwi(_grad_buf(w2p)), f8, o1_8s[0], d2_slot)
         hip.conv_wgrad(px, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
         dxb = dgrad_auto(gs, bp.pw[3], f8, gs_slot)                                          # [K+E,7,7,C] wrt the pooled crops
         # back across the pooling: gather at `planes` channels, then conv1's gradients on the feature map (s1 rides in the

@@ -84,7 +84,12 @@ int cddmsl_weight_prep_multi(const long long* table, int count, int dtype, void*
  *   y8 / q8 / amax8 (nullable together; cddmsl_conv_fwd_fp8 and cddmsl_conv_fwd_q8): a second output y8 [M][Cout] = e4m3 of
  *                         sat(y * q8[0]) for the NEXT convolution, written by the same epilogue (no separate quantisation pass);
  *                         max|y| goes to amax8.  Every amax buffer is 64 floats (atomics are spread by block; the owner takes the max).
- *   cddmsl_conv_fwd_q8    = cddmsl_conv_fwd for bf16 with that second output; only launches the 256x256 kernel takes */
+ *   cddmsl_conv_fwd_q8    = cddmsl_conv_fwd for bf16 with that second output; only launches the 256x256 kernel takes
+ *   cddmsl_conv_wgrad_fp8 dW[n][k] (f32, accumulated) += scale[n] * sum_m dy8[m][n] * im2col(x8)[m][k] on the e4m3 copies of both
+ *                         operands (x8 [Nimg][Hi][Wi][Cin], dy8 rows ldd bytes apart); "same" convolutions (stride 1, 2 pad = KH - 1),
+ *                         Cin % 256 == 0, Cout % 256 == 0 (cddmsl_conv_wgrad_fp8_ok returns 1), else CDDMSL_ERR_ARG; the caller folds
+ *                         both dequantisation factors into scale.  Replaces, for the fp8 configuration, the weight-gradient half of
+ *                         torch's conv2d backward behind modeling/backbone/clip_backbone.py:57-70 */
 int cddmsl_quantize_fp8(const void* x, void* y, const float* scale, float* amax, long numel, int src_dtype, void* stream);
 int cddmsl_conv_fwd_fp8(const void* x, const void* w, void* y, const float* scale, const float* bias, const void* residual,
                         const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int pad, int relu,
@@ -93,6 +98,9 @@ int cddmsl_conv_fwd_q8(const void* x, const void* w, void* y, const float* scale
                        const void* relu_mask, int Nimg, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
                        int relu, void* y8, const float* q8, float* amax8, void* stream);
 int cddmsl_fp8_dot_nt(const void* a, const void* b, float* c, const float* alpha, int R, int N, int K, int ldc, void* stream);
+int cddmsl_conv_wgrad_fp8_ok(int Cin, int Cout, int KH, int KW, int pad, int ldd);
+int cddmsl_conv_wgrad_fp8(const void* x8, const void* dy8, float* dw, const float* scale, int Nimg, int Hi, int Wi, int Cin, int Cout,
+                          int KH, int KW, int pad, int ldd, void* stream);
 
 /* ---- RoIAlign  (layers/roi_align.py:49-65 -> torchvision.ops.roi_align; modeling/poolers.py:190-229) --------- */
 /* y_pooled (nullable, [K][ph/2][pw/2][C], ph and pw even): AvgPool2d(2) of y, formed from the rounded outputs in the pooling

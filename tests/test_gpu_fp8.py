@@ -68,6 +68,34 @@ def test_conv_fwd_fp8_is_the_f32_product_of_the_dequantised_operands(case):
     assert int(off.sum()) == 0 and abs(float(amax.max()) - float(want.abs().max())) <= 1e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("case", [(37, 14, 14, 512, 512, 3, 1), (300, 7, 7, 256, 256, 3, 1), (2, 50, 83, 256, 512, 3, 1), (1, 5, 3, 256, 256, 3, 1),
+                                  (640, 14, 14, 512, 512, 3, 1)])
+def test_conv_wgrad_fp8_is_the_f32_product_of_the_dequantised_operands(case):
+    """k_wgrad256_f8 (ds_read_b64_tr_b8 fragments, 4-buffer LDS-DMA ring): dW = scale[n] * sum_m dy8[m, n] * im2col(x8)[m, k] on e4m3
+    bytes, against torch's f32 convolution weight gradient of the dequantised tensors; accumulating into a non-zero dW; tile counts
+    odd and even, fewer tiles than the ring is deep, rows past M, every tap's border."""
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout, KH, pad = case
+    x8 = (_rand((N, H, W, Cin), 3) * 1.5).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    d8 = (_rand((N, H, W, Cout), 4) * 0.75).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).cuda()
+    scale = (torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 0.5).cuda()
+    base = _rand((Cout, KH, KH, Cin), 6).cuda()
+    out = base.clone()
+    hip.conv_wgrad_fp8(x8, d8, (Cout, KH, KH, Cin), scale, pad=pad, out=out)
+    xp = F.pad(_deq(x8).double(), (0, 0, pad, pad, pad, pad))                               # NHWC, padded in H and W
+    df = _deq(d8).double().reshape(-1, Cout)
+    want = torch.stack([torch.stack([df.t() @ xp[:, ky:ky + H, kx:kx + W].reshape(-1, Cin) for kx in range(KH)], 1) for ky in range(KH)], 1)
+    want = base.double() + scale.double().view(-1, 1, 1, 1) * want                            # [Cout, KH, KW, Cin]
+    err = (out.double() - want).abs().max().item()
+    ref = want.abs().max().item()
+    # f32 accumulation across MFMAs, split sums in a different order -- and the MFMA's own 64-term dot product: single products are
+    # exact (subnormals included, probed one element at a time), but inside one instruction a product ~2^-12 below the row's largest is
+    # cut short (measured on the (1, 5, 3) case: 9 % of the sums, the ones holding a subnormal factor, are off by up to 1.7e-3 = 2^-9.2
+    # with products up to ~10) -- a property of v_mfma_scale_f32_32x32x64_f8f6f4, the same in the forward kernel
+    pmax = float(_deq(x8).abs().max() * _deq(d8).abs().max() * scale.max())
+    assert err <= 2e-5 * ref + 2e-4 * pmax, (case, err, ref, pmax)
+
+
 def test_bf16_conv_with_e4m3_second_output():
     """cddmsl_conv_fwd_q8: the bf16 256x256 launch whose epilogue also writes the e4m3 copy of its output"""
     from cddmsl_amd import hip
@@ -101,13 +129,15 @@ def test_fp8_dot_nt():
 
 def test_fp8_step_is_close_to_f32_step_with_forced_indices(monkeypatch):
     """BASELINE.json configs[4] as a training step: COMPUTE_DTYPE fp8 (e4m3 forward GEMMs wherever ``hip.conv_fwd_fp8_ok`` --
-    here forced on every legal conv, incl. short reductions and few tiles -- and the e4m3 region x text contraction; bf16
-    elsewhere and in the whole backward) against the exact-f32 HIP step with the f32 run's proposals forced in (same sampled
+    here forced on every legal conv, incl. short reductions and few tiles --, the e4m3 region x text contraction, the e4m3 input-gradient
+    convolutions and the e4m3 weight gradients of the 3x3 layers with 256-multiple channels, ``hip.conv_wgrad_fp8_ok``, forced on at
+    this size; bf16 elsewhere) against the exact-f32 HIP step with the f32 run's proposals forced in (same sampled
     anchors / RoIs / region picks).  Two steps: the first quantises with unit scales, the second with the scales rolled from the
     first step's recorded maxima -- the comparison is made on the SECOND.  Stated tolerance: e4m3 carries 3 mantissa bits
     (2^-4 relative per element); measured here: losses within ~2 %, gradient cosine >= 0.9918 on every backbone tensor, 0.9465 on
     the RPN's box-delta head (asserted: 6 % + 5e-3 on losses, cosine >= 0.92).  Input-gradient convolutions run in e4m3 as well."""
     monkeypatch.setenv("CDDMSL_FP8_MIN_TILES", "1")
+    monkeypatch.setenv("CDDMSL_FP8_WGRAD_MIN_M", "1")
     # (the reduction-length rule stays the production one, K >= 2048: which convolutions run in e4m3 is part of the configuration)
     from cddmsl_amd import hip, layers, synthetic
     from test_gpu_e2e import ProposalTape, _build, _cfg
@@ -142,7 +172,8 @@ def test_fp8_step_is_close_to_f32_step_with_forced_indices(monkeypatch):
     hip.PROFILE.enable()
     l8, g8, _ = run("fp8", rec * 2, 2)
     used = hip.PROFILE.collect()
-    assert used.get("k_conv_fwd256_fp8", {}).get("launches", 0) >= 20 and used.get("fp8_dot_nt", {}).get("launches", 0) >= 1, {k: v["launches"] for k, v in used.items() if "fp8" in k}
+    assert used.get("k_conv_fwd256_fp8", {}).get("launches", 0) >= 20 and used.get("fp8_dot_nt", {}).get("launches", 0) >= 1 \
+        and used.get("k_wgrad256_fp8", {}).get("launches", 0) >= 6, {k: v["launches"] for k, v in used.items() if "fp8" in k}
     worst_l = max(abs(l8[k] - f32_losses[k]) / max(abs(f32_losses[k]), 1e-2) for k in f32_losses)
     errs = []
     for k, r in f32_grads.items():
