@@ -55,6 +55,15 @@ __device__ __forceinline__ unsigned wave_max_u(unsigned v) {
   return v;
 }
 
+// four f32 -> four OCP e4m3 bytes (v_cvt_pk_fp8_f32, gfx950), clamped to the format's finite range first (e4m3fn has no infinity)
+__device__ __forceinline__ unsigned e4m3x4(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+
 static inline int launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? CDDMSL_OK : CDDMSL_ERR_LAUNCH;

@@ -160,6 +160,46 @@ __global__ void k_avgpool2_bwd(const char* dy, const char* mask, const char* add
   }
 }
 
+// fp8 configuration: the same pass (bf16) also writes the e4m3 copy of dx for the GEMMs that consume it -- y8 = sat(dx * q8[0]), from
+// the f32 value -- and max-es |dx| into amax8[block & 63] (delayed scaling; see fp8.hip)
+__global__ __launch_bounds__(256) void k_avgpool2_bwd_q8(const char* dy, const char* mask, const char* add, char* dx, int N, int H, int W, int cch,
+                                                         char* y8, const float* q8, unsigned* amax8) {
+  using T = __bf16;
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)N * H * W * cch;
+  const float s = q8[0];
+  unsigned mx = 0u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c = i % cch; long q = i / cch;
+    int xx = q % W; q /= W;
+    int yy = q % H; int n = q / H;
+    float g[8], m[8], a[8], o[8];
+    bool in = (yy >> 1) < Ho && (xx >> 1) < Wo;
+    if (in) Elt<T>::unpack(((const u32x4*)dy)[(((long)n * Ho + (yy >> 1)) * Wo + (xx >> 1)) * cch + c], g);
+    if (mask) Elt<T>::unpack(((const u32x4*)mask)[i], m);
+    if (add) Elt<T>::unpack(((const u32x4*)add)[i], a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = in ? g[j] * 0.25f : 0.f;
+      if (add) v += a[j];
+      if (mask && !(m[j] > 0.f)) v = 0.f;
+      o[j] = v;
+      mx = absmax_bits(mx, v);
+    }
+    ((u32x4*)dx)[i] = Elt<T>::pack(o);
+    const u32x2 o8 = {e4m3x4(o[0] * s, o[1] * s, o[2] * s, o[3] * s), e4m3x4(o[4] * s, o[5] * s, o[6] * s, o[7] * s)};
+    ((u32x2*)y8)[i] = o8;
+  }
+  __shared__ unsigned sm[4];
+  mx = wave_max_u(mx);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned a = sm[0] > sm[1] ? sm[0] : sm[1], b = sm[2] > sm[3] ? sm[2] : sm[3];
+    atomicMax(amax8 + (blockIdx.x & 63), a > b ? a : b);
+  }
+}
+
 // ---------------------------------------------------------------- stock ResNet pieces (config #1: detectron2 R50-C4)
 // F.max_pool2d(x, 3, stride 2, padding 1)  (BasicStem, modeling/backbone/resnet.py:355-358), NHWC, forward only (stem frozen)
 template <typename T>
@@ -597,6 +637,17 @@ extern "C" int cddmsl_avgpool2_bwd(const void* dy, const void* mask, const void*
   if (total == 0) return CDDMSL_OK;
   DISPATCH(dtype, k_avgpool2_bwd, <<<dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream>>>(
       (const char*)dy, (const char*)mask, (const char*)add, (char*)dx, N, H, W, cch));
+  return launch_status();
+}
+
+extern "C" int cddmsl_avgpool2_bwd_q8(const void* dy, const void* mask, const void* add, void* dx, int N, int H, int W, int C, void* y8,
+                                      const float* q8, float* amax8, void* stream) {
+  if ((C * 2) % 16 || !y8 || !q8 || !amax8) return CDDMSL_ERR_ARG;
+  const int cch = C * 2 / 16;
+  const long total = (long)N * H * W * cch;
+  if (total == 0) return CDDMSL_OK;
+  hipLaunchKernelGGL(k_avgpool2_bwd_q8, dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)mask, (const char*)add,
+                     (char*)dx, N, H, W, cch, (char*)y8, q8, (unsigned*)amax8);
   return launch_status();
 }
 

@@ -1677,8 +1677,9 @@ __global__ __launch_bounds__(512) void k_wgrad256(WgradArgs p) {
 // ds_read_b64_tr_b8 (tools/tr_b8_probe.hip: per 16 lanes a block of 8 rows x 16 columns of bytes, lane 2q+p supplies row q columns
 // 8p.., lane i receives column i) -- lane half h takes pixels 32h..32h+31 of the tile in 4 reads, for both operands alike, which is
 // all a dot product needs; a 32-lane half touches 8 rows x 32 contiguous bytes whose chunk pairs the XOR spreads over all 64 banks.
-// Loop: a ring of 4 LDS buffers filled by LDS-DMA two tiles ahead (counted vmcnt), ONE barrier per tile, the 24 fragment reads of
-// tile t+1 issued between the 8 MFMAs of tile t into a second register set.
+// Loop: a ring of 4 LDS buffers filled by LDS-DMA two tiles ahead (counted vmcnt), ONE barrier per tile, fragment reads issued between
+// the MFMAs one half tile ahead (register plan below).  The same loop on bf16 operands (32-pixel tiles, ds_read_b64_tr_b16) was built and
+// measured against k_wgrad256's ping-pong phases: 19.3-20.1 vs 17.7 ms per step for the same launches -- the bf16 kernel keeps its phases.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_wgrad256_f8(WgradArgs p) {
   __shared__ __attribute__((aligned(16))) u32x4 lds[4 * 2 * 64 * 16];   // byte = ring<<15 | ab<<14 | row*256 + slot*16
@@ -1812,6 +1813,7 @@ __global__ __launch_bounds__(512) void k_wgrad256_f8(WgradArgs p) {
       // (behind the last tile: a buffer of the ring that holds an older tile -- read and never used)
       const unsigned ro = (unsigned)((kt + 1) & 3) << 15;
       const unsigned a0 = adA[0] + ro, a1 = adA[1] + ro, b0 = adB[0] + ro, b1 = adB[1] + ro;
+      // (one fragment per MFMA: issuing all four up front measured slower, 5.14 vs 4.98 ms for the RoI head's three launches)
       CDDMSL_TR8x4(fa[0], a0)
       mma(IS{}, I2{}, I0{});
       CDDMSL_TR8x4(fa[1], a1)

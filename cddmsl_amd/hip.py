@@ -36,6 +36,7 @@ def _L():
         L.cddmsl_preprocess224.argtypes = [vp, vp] + [ci] * 11 + [vp, vp, ci, vp]
         L.cddmsl_avgpool2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
         L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
+        L.cddmsl_avgpool2_bwd_q8.argtypes = [vp] * 4 + [ci] * 4 + [vp] * 4
         L.cddmsl_attn_tokens_fwd.argtypes = [vp] * 3 + [ci] * 5 + [vp]
         L.cddmsl_attn_tokens_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_attnpool_softmax_fwd.argtypes = [vp] * 3 + [c_long, ci, ci, ci, cf, ci, vp]
@@ -52,6 +53,8 @@ def _L():
         L.cddmsl_roi_align_backward_nchw_anyorder.argtypes = [vp] * 3 + [ci] * 7 + [cf, ci, ci, ci, vp, vp, vp]
         L.cddmsl_quantize_fp8.argtypes = [vp] * 4 + [c_long, ci, vp]
         L.cddmsl_conv_fwd_fp8.argtypes = [vp] * 7 + [ci] * 10 + [vp] * 4
+        L.cddmsl_conv_wgrad_fp8_ok.argtypes = [ci] * 6
+        L.cddmsl_conv_wgrad_fp8.argtypes = [vp] * 4 + [ci] * 9 + [vp]
         L.cddmsl_conv_fwd_q8.argtypes = [vp] * 7 + [ci] * 10 + [vp] * 4
         L.cddmsl_fp8_dot_nt.argtypes = [vp] * 4 + [ci] * 4 + [vp]
         L.cddmsl_roi_align_forward_affine.argtypes = [vp] * 6 + [ci] * 8 + [cf, ci, ci, ci] + [vp] * 4
@@ -492,12 +495,19 @@ def avgpool2_fwd(x):
 
 
 @_timed("avgpool2_bwd")
-def avgpool2_bwd(dy, in_shape, mask=None, add=None):
-    """dx = up(dy)/4 (+ add), zeroed where mask <= 0.  in_shape = (N,H,W,C) of the pooled tensor's input."""
+def avgpool2_bwd(dy, in_shape, mask=None, add=None, emit8=None):
+    """dx = up(dy)/4 (+ add), zeroed where mask <= 0.  in_shape = (N,H,W,C) of the pooled tensor's input.  ``emit8`` (scale, amax),
+    bf16 only: the pass also writes dx's e4m3 copy (attached as ``dx._fp8``) and records max|dx|."""
     require_cuda(dy, mask, add)
     N, H, W, C = in_shape
     assert dy.is_contiguous() and tuple(dy.shape) == (N, H // 2, W // 2, C)
     dx = torch.empty(in_shape, device=dy.device, dtype=dy.dtype)
+    if emit8 is not None and dy.dtype == torch.bfloat16:
+        y8 = torch.empty(in_shape, device=dy.device, dtype=torch.uint8)
+        check(_L().cddmsl_avgpool2_bwd_q8(ptr(dy), ptr(mask), ptr(add), ptr(dx), N, H, W, C, ptr(y8), ptr(emit8[0]), ptr(emit8[1]), stream_ptr()),
+              "cddmsl_avgpool2_bwd_q8")
+        dx._fp8 = (y8, emit8[0].data_ptr())
+        return dx
     check(_L().cddmsl_avgpool2_bwd(ptr(dy), ptr(mask), ptr(add), ptr(dx), N, H, W, C, _dt(dy), stream_ptr()), "cddmsl_avgpool2_bwd")
     return dx
 

@@ -564,7 +564,7 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None, o1
     hip.conv_wgrad(p2 if pool else o2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
     if pool:
         dp2 = dgrad_auto(gs, bp.pw[2], f8, gs_slot)
-        dpre2 = hip.avgpool2_bwd(dp2, tuple(o2.shape), mask=o2)
+        dpre2 = hip.avgpool2_bwd(dp2, tuple(o2.shape), mask=o2, emit8=d2_slot.emit() if f8 and _fp8_dgrad_wanted(bp.pw[1], o2.shape, 1, f8) else None)
     else:
         e8 = d2_slot.emit() if f8 and _fp8_dgrad_wanted(bp.pw[1], o2.shape, 1, f8) else None
         dpre2 = dgrad_auto(gs, bp.pw[2], f8, gs_slot, emit8=e8, relu_mask=o2)
@@ -739,7 +739,8 @@ class RoIStageFn(torch.autograd.Function):
         gs_slot = fp8_slot_of(bp, "_fp8_gs") if f8 else None
         d2_slot = fp8_slot_of(bp.pw[1], "_fp8_g") if f8 else None
         hip.conv_wgrad(p2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
-        dpre2 = hip.avgpool2_bwd(dgrad_auto(gs, bp.pw[2], f8, gs_slot), tuple(o2.shape), mask=o2)
+        e8 = d2_slot.emit() if f8 and _fp8_dgrad_wanted(bp.pw[1], o2.shape, 1, f8) else None   # (the e4m3 copy conv2's two gradient GEMMs read)
+        dpre2 = hip.avgpool2_bwd(dgrad_auto(gs, bp.pw[2], f8, gs_slot), tuple(o2.shape), mask=o2, emit8=e8)
         dpre1 = dgrad_auto(dpre2, bp.pw[1], f8, d2_slot, pad=1, relu_mask=o1)                # [K+E,14,14,planes] wrt bn1's output
         wgrad_auto(o1, dpre2, bp.pw[1], s2, 1, _ohwi(_grad_buf(w2p)), f8, o1_8s[0], d2_slot)
         hip.conv_wgrad(px, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))

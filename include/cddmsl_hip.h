@@ -252,6 +252,9 @@ int cddmsl_preprocess224(const unsigned char* img, void* out, int n, int h, int 
 int cddmsl_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 int cddmsl_avgpool2_bwd(const void* dy, const void* mask, const void* add, void* dx, int N, int H, int W, int C, int dtype,
                         void* stream);
+/* fp8 configuration: the same pass (bf16 only) with a second output, y8 = e4m3 of sat(dx * q8[0]), max|dx| recorded in amax8 (64 floats) */
+int cddmsl_avgpool2_bwd_q8(const void* dy, const void* mask, const void* add, void* dx, int N, int H, int W, int C, void* y8,
+                           const float* q8, float* amax8, void* stream);
 /* stock Detectron2 R50-C4 pieces (config #1): BasicStem max-pool (modeling/backbone/resnet.py:355-358), the input-gradient
  * scatter of stride-2 1x1 convs (STRIDE_IN_1X1 bottlenecks, resnet.py:100-210), Res5ROIHeads mean pool (roi_heads.py:487) */
 int cddmsl_maxpool3s2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);

@@ -96,6 +96,25 @@ def test_conv_wgrad_fp8_is_the_f32_product_of_the_dequantised_operands(case):
     assert err <= 2e-5 * ref + 2e-4 * pmax, (case, err, ref, pmax)
 
 
+def test_avgpool2_bwd_with_e4m3_second_output():
+    """AvgPool2d(2) backward (+ ReLU mask) writing the e4m3 copy of its result in the same pass: the bf16 result is the plain
+    kernel's, the copy is the quantiser's on the f32 value (<= 1 code from quantising the bf16 result), the maximum is recorded."""
+    from cddmsl_amd import hip
+    N, H, W, C = 3, 14, 14, 64
+    dy = _rand((N, H // 2, W // 2, C), 21).bfloat16().cuda()
+    mask = _rand((N, H, W, C), 22).bfloat16().cuda()
+    q, amax = torch.tensor([37.0], device="cuda"), torch.zeros(64, device="cuda")
+    want = hip.avgpool2_bwd(dy, (N, H, W, C), mask=mask)
+    got = hip.avgpool2_bwd(dy, (N, H, W, C), mask=mask, emit8=(q, amax))
+    assert torch.equal(got, want)
+    f = dy.float().repeat_interleave(2, 1).repeat_interleave(2, 2) * 0.25 * (mask.float() > 0)
+    want8 = (f * 37.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    got8 = got._fp8[0]
+    off = (got8 != want8) & ~(((got8 & 0x7f) == 0) & ((want8 & 0x7f) == 0))
+    assert int(off.sum()) == 0 and got._fp8[1] == q.data_ptr()
+    assert float(amax.max()) == float(f.abs().max())
+
+
 def test_bf16_conv_with_e4m3_second_output():
     """cddmsl_conv_fwd_q8: the bf16 256x256 launch whose epilogue also writes the e4m3 copy of its output"""
     from cddmsl_amd import hip
