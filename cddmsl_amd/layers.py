@@ -249,14 +249,14 @@ def fp8_copy(t, slot):
     return t8
 
 
-def wgrad_auto(x, dy, pw, scale, pad, out, fp8=False, x8=None, dy_slot=None):
+def wgrad_auto(x, dy, pw, scale, pad, out, fp8=False, x8=None, dy_slot=None, min_m=None):
     """Weight gradient of a stride-1 convolution: ``hip.conv_wgrad`` on the bf16 / f32 tensors, or -- fp8 configuration, shapes
     ``hip.conv_wgrad_fp8_ok`` takes -- the e4m3 kernel on the activation's copy kept from the forward pass (``x8``, made under
     ``fp8_act_slot(pw)``) and the gradient's copy under ``dy_slot`` (the one its input-gradient convolution reads); both
     dequantisation factors ride in the per-channel scale."""
     Cout, KH, KW, Cin = _ohwi(pw.param).shape
     if fp8 and x8 is not None and dy_slot is not None and dy.dtype == torch.bfloat16 \
-            and hip.conv_wgrad_fp8_ok(dy.numel() // Cout, Cin, Cout, KH, KW, pad):
+            and hip.conv_wgrad_fp8_ok(dy.numel() // Cout, Cin, Cout, KH, KW, pad, min_m):
         d8 = fp8_copy(dy, dy_slot)
         deq = fp8_act_slot(pw).deq * dy_slot.deq
         eff = deq * scale if scale is not None else deq.expand(Cout).contiguous()
@@ -374,13 +374,18 @@ class ConvFn(torch.autograd.Function):
         y = conv_fwd_auto(x, pw, None, None if bias is None else bias.detach(), fp8, residual=None if residual is None else residual.detach(),
                           relu=relu, stride=stride, pad=pad, out_f32=out_f32)
         ctx.pw, ctx.bias, ctx.cfg = pw, bias, (stride, pad, relu, out_f32, train_w)
-        ctx.save_for_backward(x, y if relu else None)
+        # fp8 configuration: where the forward ran on the e4m3 kernel, its input copy is kept for the weight gradient
+        ctx.fp8 = bool(fp8)
+        ctx.save_for_backward(x, y if relu else None, _fp8_made_for(x, pw) if fp8 else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y = ctx.saved_tensors
+        x, y, x8 = ctx.saved_tensors
         stride, pad, relu, out_f32, train_w = ctx.cfg
+        # (fp8 configuration, only where the forward took the e4m3 kernel: one e4m3 copy of the gradient feeds both gradient GEMMs)
+        f8 = ctx.fp8 and x8 is not None and stride == 1
+        g_slot = fp8_slot_of(ctx.pw, "_fp8_g") if f8 else None
         T = x.dtype
         dy_in = dy
         dy = dy.contiguous()
@@ -390,7 +395,10 @@ class ConvFn(torch.autograd.Function):
             dy = dy.to(T)
         w = ctx.pw.param
         if train_w:
-            hip.conv_wgrad(x, dy, _ohwi(w).shape, None, stride=stride, pad=pad, out=_ohwi(_grad_buf(w)))
+            if f8:
+                wgrad_auto(x, dy, ctx.pw, None, pad, _ohwi(_grad_buf(w)), True, x8, g_slot, min_m=65536)
+            else:
+                hip.conv_wgrad(x, dy, _ohwi(w).shape, None, stride=stride, pad=pad, out=_ohwi(_grad_buf(w)))
             if ctx.bias is not None:
                 hip.colsum(dy.view(-1, dy.shape[-1]), out=_grad_buf(ctx.bias))
         dx = None
@@ -406,6 +414,8 @@ class ConvFn(torch.autograd.Function):
                 part = torch.empty(S, rows, N, device=dy.device, dtype=torch.float32)
                 hip.gemm_nt_batched(dy, wd, part, rows, N, Kd // S, Kd, Kd, N, S, Kd // S, Kd // S, rows * N)
                 dx = part.sum(0).to(T).view(x.shape)
+            elif f8:
+                dx = dgrad_auto(dy, ctx.pw, True, g_slot, pad=KH - 1 - pad)
             else:
                 dx = hip.conv_fwd(dy, wd, stride=1, pad=KH - 1 - pad)
         # y = conv + residual (no ReLU with a residual): the residual's gradient is the incoming one, as it came
@@ -450,7 +460,8 @@ def frozen_mlp(x2d, pw1, b1, pw2, b2, residual):
 
 def conv(x, pw, bias=None, stride=1, pad=0, relu=False, out_f32=False, train_w=True, residual=None, fp8=False):
     """``residual`` (same shape as the output; f32 with ``out_f32`` on the bf16 path) is added in the GEMM epilogue.
-    ``fp8``: forward on e4m3 operands where the shape qualifies (``conv_fwd_auto``); backward unchanged (bf16)."""
+    ``fp8``: forward on e4m3 operands where the shape qualifies (``conv_fwd_auto``), and then both gradient GEMMs where theirs do
+    (``wgrad_auto`` / ``dgrad_auto``: the RPN's 3x3 convolution)."""
     anchor = pw.param if train_w else None
     assert residual is None or not relu
     return ConvFn.apply(x, anchor, pw, bias, stride, pad, relu, out_f32, train_w, residual, fp8)
