@@ -394,13 +394,13 @@ def conv_wgrad(x, dy, w_shape, scale=None, stride=1, pad=0, pool=False, out=None
     return out
 
 
-def conv_wgrad_fp8_ok(M, Cin, Cout, KH, KW, pad, min_m=None):
-    """shapes the e4m3 weight-gradient kernel takes AND wins on: whole 256 x 256 output tiles of a "same" convolution with taps (a
-    1x1 layer's weight gradient is bound by reading its operands once, which the bf16 kernel does at the same rate per byte only for
-    twice the bytes -- the copies it would need are not all there) and a reduction long enough to fill the chip"""
+def conv_wgrad_fp8_ok(M, Cin, Cout, KH, KW, pad, min_m=None, taps_only=True):
+    """shapes the e4m3 weight-gradient kernel takes AND wins on: whole 256 x 256 output tiles of a "same" convolution and a reduction
+    long enough to fill the chip.  ``taps_only``: 1x1 layers only where the caller says their e4m3 copies come for free (written by the
+    producing epilogues: the RoI head's conv1 / conv3); the kernel itself runs ~2x the bf16 one on every shape measured."""
     # (default: the RoI head's 3x3 layers; a caller whose copies cost nothing extra passes its own bound; tests lower it to reach the kernel at small sizes)
     min_m = int(os.environ.get("CDDMSL_FP8_WGRAD_MIN_M", "300000" if min_m is None else str(min_m)))
-    return os.environ.get("CDDMSL_FP8_WGRAD", "1") != "0" and KH * KW > 1 and M >= min_m \
+    return os.environ.get("CDDMSL_FP8_WGRAD", "1") != "0" and (KH * KW > 1 or not taps_only) and M >= min_m \
         and bool(_L().cddmsl_conv_wgrad_fp8_ok(Cin, Cout, KH, KW, pad, Cout))
 
 

@@ -249,19 +249,28 @@ def fp8_copy(t, slot):
     return t8
 
 
-def wgrad_auto(x, dy, pw, scale, pad, out, fp8=False, x8=None, dy_slot=None, min_m=None):
+def wgrad_auto(x, dy, pw, scale, pad, out, fp8=False, x8=None, dy_slot=None, min_m=None, taps_only=True):
     """Weight gradient of a stride-1 convolution: ``hip.conv_wgrad`` on the bf16 / f32 tensors, or -- fp8 configuration, shapes
     ``hip.conv_wgrad_fp8_ok`` takes -- the e4m3 kernel on the activation's copy kept from the forward pass (``x8``, made under
     ``fp8_act_slot(pw)``) and the gradient's copy under ``dy_slot`` (the one its input-gradient convolution reads); both
     dequantisation factors ride in the per-channel scale."""
     Cout, KH, KW, Cin = _ohwi(pw.param).shape
     if fp8 and x8 is not None and dy_slot is not None and dy.dtype == torch.bfloat16 \
-            and hip.conv_wgrad_fp8_ok(dy.numel() // Cout, Cin, Cout, KH, KW, pad, min_m):
+            and hip.conv_wgrad_fp8_ok(dy.numel() // Cout, Cin, Cout, KH, KW, pad, min_m, taps_only):
         d8 = fp8_copy(dy, dy_slot)
         deq = fp8_act_slot(pw).deq * dy_slot.deq
         eff = deq * scale if scale is not None else deq.expand(Cout).contiguous()
         return hip.conv_wgrad_fp8(x8, d8, (Cout, KH, KW, Cin), eff, pad=pad, out=out)
     return hip.conv_wgrad(x, dy, (Cout, KH, KW, Cin), scale, pad=pad, out=out)
+
+
+def _fp8_wgrad1x1_wanted(pw, M, fp8):
+    """fp8 configuration: does the weight gradient of the 1x1 convolution ``pw`` over M rows take the e4m3 kernel (so that the
+    launches producing its two operands should write their e4m3 copies)?"""
+    if not fp8 or os.environ.get("CDDMSL_FP8_WGRAD_1X1", "1") == "0":
+        return False
+    Cout, KH, KW, Cin = _ohwi(pw.param).shape
+    return KH == 1 and KW == 1 and hip.conv_wgrad_fp8_ok(M, Cin, Cout, 1, 1, 0, None, False)
 
 
 def _fp8_made_for(t, pw):
@@ -543,7 +552,12 @@ def _block_forward(x, bp, save, px_given=None, next_pw=None, out_spec=None):
     f8 = bp.fp8
     o1_shape = (x.shape[0], x.shape[1], x.shape[2], _ohwi(bp.w[0]).shape[0])
     o1 = conv_fwd_auto(x, bp.pw[0], s1, b1, f8, emit8=fp8_emit_for(bp.pw[1], o1_shape, 1, f8), relu=True)     # (conv2 reads o1's e4m3 copy)
-    o2 = conv_fwd_auto(o1, bp.pw[1], s2, b2, f8, relu=True, pad=1)
+    x8 = _fp8_made_for(x, bp.pw[0]) if f8 and save else None                                # (conv1's e4m3 input copy, for its weight gradient)
+    M2 = x.shape[0] * x.shape[1] * x.shape[2]
+    # conv3's weight gradient on e4m3 operands needs o2's copy: written by conv2's epilogue under conv3's activation slot
+    e8o2 = fp8_act_slot(bp.pw[2]).emit() if save and not pool and _fp8_wgrad1x1_wanted(bp.pw[2], M2, f8) else None
+    o2 = conv_fwd_auto(o1, bp.pw[1], s2, b2, f8, emit8=e8o2, relu=True, pad=1)
+    o2_8 = _fp8_made_for(o2, bp.pw[2]) if e8o2 is not None else None
     p2 = hip.avgpool2_fwd(o2) if pool else o2
     if pool and px_given is not None and tuple(px_given.shape) == (x.shape[0], x.shape[1] // 2, x.shape[2] // 2, x.shape[3]):
         px = px_given                              # the producer of x pooled it on the way (roi_align with_pooled)
@@ -555,10 +569,10 @@ def _block_forward(x, bp, save, px_given=None, next_pw=None, out_spec=None):
         idn = x
     out_shape = (p2.shape[0], p2.shape[1], p2.shape[2], _ohwi(bp.w[2]).shape[0])
     out = conv_fwd_auto(p2, bp.pw[2], s3, b3, f8, emit8=fp8_emit_for(next_pw, out_shape, 0, f8), residual=idn, relu=True, out_spec=out_spec)
-    return out, ((o1, o2, p2 if pool else None, px if pool else None, _fp8_made_for(o1, bp.pw[1]) if f8 else None) if save else None)
+    return out, ((o1, o2, p2 if pool else None, px if pool else None, (x8, _fp8_made_for(o1, bp.pw[1]) if f8 else None, o2_8)) if save else None)
 
 
-def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None, o1_8=None):
+def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None, c8=(None, None, None)):
     """gs = dL/d(pre-ReLU sum) of this block (already masked by out>0).  Returns dL/dx, masked by x>0 when
     ``mask_x`` (x is the previous block's post-ReLU output) so it is directly the previous block's ``gs``.
     fp8 configuration: the input-gradient convolutions with a long reduction (conv3's, conv2's, the downsample conv's) run on
@@ -572,7 +586,13 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None, o1
     shp = lambda w: _ohwi(w).shape
     gs_slot = fp8_slot_of(bp, "_fp8_gs") if f8 else None
     d2_slot = fp8_slot_of(bp.pw[1], "_fp8_g") if f8 else None
-    hip.conv_wgrad(p2 if pool else o2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
+    x8, o1_8, o2_8 = c8                               # e4m3 copies kept from the forward pass (fp8 configuration): inputs of conv1, conv2, conv3
+    M2 = o2.shape[0] * o2.shape[1] * o2.shape[2]
+    if o2_8 is not None and not pool:
+        wgrad_auto(o2, gs, bp.pw[2], s3, 0, _ohwi(_grad_buf(w3p)), f8, o2_8, gs_slot, taps_only=False)
+    else:
+        hip.conv_wgrad(p2 if pool else o2, gs, shp(w3p), s3, out=_ohwi(_grad_buf(w3p)))
+    d1_slot = fp8_slot_of(bp.pw[0], "_fp8_g") if f8 and x8 is not None and _fp8_wgrad1x1_wanted(bp.pw[0], M2, f8) else None
     if pool:
         dp2 = dgrad_auto(gs, bp.pw[2], f8, gs_slot)
         dpre2 = hip.avgpool2_bwd(dp2, tuple(o2.shape), mask=o2, emit8=d2_slot.emit() if f8 and _fp8_dgrad_wanted(bp.pw[1], o2.shape, 1, f8) else None)
@@ -580,9 +600,12 @@ def _block_backward(gs, x, o1, o2, p2, px, bp, need_dx, mask_x, prev_bp=None, o1
         e8 = d2_slot.emit() if f8 and _fp8_dgrad_wanted(bp.pw[1], o2.shape, 1, f8) else None
         dpre2 = dgrad_auto(gs, bp.pw[2], f8, gs_slot, emit8=e8, relu_mask=o2)
     # (conv2's input gradient first: it leaves the e4m3 copy of dpre2 attached, which the fp8 weight gradient reads as well)
-    dpre1 = dgrad_auto(dpre2, bp.pw[1], f8, d2_slot, pad=1, relu_mask=o1)
+    dpre1 = dgrad_auto(dpre2, bp.pw[1], f8, d2_slot, pad=1, relu_mask=o1, emit8=d1_slot.emit() if d1_slot is not None else None)
     wgrad_auto(o1, dpre2, bp.pw[1], s2, 1, _ohwi(_grad_buf(w2p)), f8, o1_8, d2_slot)
-    hip.conv_wgrad(x, dpre1, shp(w1p), s1, out=_ohwi(_grad_buf(w1p)))
+    if d1_slot is not None:
+        wgrad_auto(x, dpre1, bp.pw[0], s1, 0, _ohwi(_grad_buf(w1p)), f8, x8, d1_slot, taps_only=False)
+    else:
+        hip.conv_wgrad(x, dpre1, shp(w1p), s1, out=_ohwi(_grad_buf(w1p)))
     if wdp is not None:
         hip.conv_wgrad(px if pool else x, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
     if not need_dx:
@@ -614,22 +637,22 @@ class ResStageFn(torch.autograd.Function):
             cur, mids = _block_forward(cur, bp, True, px0 if bi == 0 else None, blocks[bi + 1].pw[0] if bi + 1 < len(blocks) else None,
                                        out_spec if bi + 1 == len(blocks) else None)
             saved += [mids[0], mids[1], mids[2], mids[3], cur]
-            o1_8s.append(mids[4])
+            o1_8s += list(mids[4])
         ctx.blocks = blocks
-        ctx.save_for_backward(*saved, *o1_8s)         # (fp8 configuration: conv2's e4m3 input copies, for its weight gradient)
+        ctx.save_for_backward(*saved, *o1_8s)         # (fp8 configuration: three e4m3 input copies per block, for the weight gradients)
         return cur
 
     @staticmethod
     def backward(ctx, g):
         blocks = ctx.blocks
-        saved, o1_8s = ctx.saved_tensors[:-len(blocks)], ctx.saved_tensors[-len(blocks):]
+        saved, o1_8s = ctx.saved_tensors[:-3 * len(blocks)], ctx.saved_tensors[-3 * len(blocks):]
         need_dx = ctx.needs_input_grad[0]
         # mask by the stage output's ReLU -- unless the one consumer of the output has done it (res_stage_attnpool)
         gs = g.contiguous() if ctx.out_grad_premasked else hip.relu_bwd(g.contiguous(), saved[-1])
         for i in range(len(blocks) - 1, -1, -1):
             x, o1, o2, p2, px = saved[5 * i: 5 * i + 5]
             gs = _block_backward(gs, x, o1, o2, p2, px, blocks[i], need_dx or i > 0, mask_x=i > 0, prev_bp=blocks[i - 1] if i > 0 else None,
-                                 o1_8=o1_8s[i])
+                                 c8=tuple(o1_8s[3 * i: 3 * i + 3]))
         return gs, None, None, None, None, None
 
 
@@ -719,26 +742,26 @@ class RoIStageFn(torch.autograd.Function):
         feat = feat.contiguous()
         nxt = lambda i: blocks[i + 1].pw[0] if i + 1 < len(blocks) else None
         o1, o2, p2, px, cur, o1_8 = _roi_block0_forward(feat, rois, blocks[0], out_size, scale, sr, extra, nxt(0))
-        saved, o1_8s = [feat, rois, roi_start, extra, o1, o2, p2, px, cur], [o1_8]
+        saved, o1_8s = [feat, rois, roi_start, extra, o1, o2, p2, px, cur], [None, o1_8, None]
         for bi, bp in enumerate(blocks[1:], start=1):
             cur, mids = _block_forward(cur, bp, True, None, nxt(bi))
             saved += [mids[0], mids[1], mids[2], mids[3], cur]
-            o1_8s.append(mids[4])
+            o1_8s += list(mids[4])
         ctx.blocks, ctx.meta = blocks, (out_size, scale, sr, out_grad_premasked)
-        ctx.save_for_backward(*saved, *o1_8s)         # (fp8 configuration: conv2's e4m3 input copies, for its weight gradient)
+        ctx.save_for_backward(*saved, *o1_8s)         # (fp8 configuration: three e4m3 input copies per block, for the weight gradients)
         return cur
 
     @staticmethod
     def backward(ctx, g):
         blocks = ctx.blocks
-        saved, o1_8s = ctx.saved_tensors[:-len(blocks)], ctx.saved_tensors[-len(blocks):]
+        saved, o1_8s = ctx.saved_tensors[:-3 * len(blocks)], ctx.saved_tensors[-3 * len(blocks):]
         out_size, scale, sr, premasked = ctx.meta
         feat, rois, roi_start, extra = saved[:4]
         st = saved[4:]                               # per block: o1, o2, p2, px, out
         gs = g.contiguous() if premasked else hip.relu_bwd(g.contiguous(), st[-1])
         for i in range(len(blocks) - 1, 0, -1):
             o1, o2, p2, px = st[5 * i: 5 * i + 4]
-            gs = _block_backward(gs, st[5 * i - 1], o1, o2, p2, px, blocks[i], True, mask_x=True, prev_bp=blocks[i - 1], o1_8=o1_8s[i])
+            gs = _block_backward(gs, st[5 * i - 1], o1, o2, p2, px, blocks[i], True, mask_x=True, prev_bp=blocks[i - 1], c8=tuple(o1_8s[3 * i: 3 * i + 3]))
         bp = blocks[0]
         o1, o2, p2, px = st[0:4]
         T = o1.dtype
@@ -753,7 +776,7 @@ class RoIStageFn(torch.autograd.Function):
         e8 = d2_slot.emit() if f8 and _fp8_dgrad_wanted(bp.pw[1], o2.shape, 1, f8) else None   # (the e4m3 copy conv2's two gradient GEMMs read)
         dpre2 = hip.avgpool2_bwd(dgrad_auto(gs, bp.pw[2], f8, gs_slot), tuple(o2.shape), mask=o2, emit8=e8)
         dpre1 = dgrad_auto(dpre2, bp.pw[1], f8, d2_slot, pad=1, relu_mask=o1)                # [K+E,14,14,planes] wrt bn1's output
-        wgrad_auto(o1, dpre2, bp.pw[1], s2, 1, _ohwi(_grad_buf(w2p)), f8, o1_8s[0], d2_slot)
+        wgrad_auto(o1, dpre2, bp.pw[1], s2, 1, _ohwi(_grad_buf(w2p)), f8, o1_8s[1], d2_slot)
         hip.conv_wgrad(px, gs, shp(wdp), bnd[0], out=_ohwi(_grad_buf(wdp)))
         dxb = dgrad_auto(gs, bp.pw[3], f8, gs_slot)                                          # [K+E,7,7,C] wrt the pooled crops
         # back across the pooling: gather at `planes` channels, then conv1's gradients on the feature map (s1 rides in the
