@@ -35,7 +35,12 @@ def init_distributed(backend=None):
         # (RCCL needs one device per rank: the shared-GPU rehearsal of the N > 1 path runs over gloo)
         backend = backend or os.environ.get("CDDMSL_DIST_BACKEND") or (
             "nccl" if torch.cuda.is_available() and not os.environ.get("CDDMSL_SHARE_GPU") else "gloo")
-        dist.init_process_group(backend)
+        opts = None
+        if backend == "nccl" and os.environ.get("CDDMSL_RCCL_HIGH_PRIORITY") == "1":
+            # opt-in A/B knob for the first multi-GPU runs: RCCL's kernels on a high-priority stream, so that they get the CUs the
+            # compute kernels release first (the persistent conv kernels hold every CU for their whole launch: DESIGN.md section 5)
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group(backend, pg_options=opts)
     return get_rank(), get_world_size()
 
 
