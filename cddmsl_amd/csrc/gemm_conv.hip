@@ -102,6 +102,7 @@ struct ConvArgs {
   // launch stops at this logical tile (persistent form; the one-tile grid is simply shorter).
   float* partial = nullptr;
   int tile0 = 0, ksplits = 1, kper = 0, tile_limit = 0;
+  int nt_out = 1;  // bf16 output stored non-temporal (CDDMSL_STORE_AUX): outputs too large to be found in the caches by their consumer
 #ifdef CDDMSL_STAMPS
   unsigned long long* stamps;   // diagnostic build only (scratch/k256.hip): per-wave cycle sums of the phase segments
 #endif
@@ -2288,7 +2289,8 @@ __device__ __forceinline__ void tile_epilogue(const ConvArgs& p, f32x16 (&acc)[4
         asm volatile("" :: "v"(o0), "v"(o1));
       } else {
         const u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
-        __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, CDDMSL_STORE_AUX);
+        if (p.nt_out) __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, CDDMSL_STORE_AUX);
+        else __builtin_amdgcn_raw_buffer_store_b128(o, ry, vy, so, 0);
         asm volatile("s_nop 4" ::: "memory");
         asm volatile("" :: "v"(o));
       }
@@ -3053,6 +3055,11 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
   a.tstamps = g_tile_stamps;
 #endif
   if (a.M == 0) return CDDMSL_OK;
+  {               // outputs up to this many MiB are stored with the default policy (their consumer may still find them in the 256 MiB last-level cache)
+    // (same-box A/B of the training step, 3 runs each: never 102.38 ms, always 101.60, above 128 MiB 101.66; on another box 100 MiB was 0.4 ms ahead of always)
+    static const long nt_min_mb = getenv("CDDMSL_NT_MIN_MB") ? atol(getenv("CDDMSL_NT_MIN_MB")) : 128;
+    a.nt_out = (long)a.M * Cout * 2 > (nt_min_mb << 20) ? 1 : 0;
+  }
   if (y8) {       // e4m3 second output: bf16 launches of the 256x256 kernel only (its epilogue writes it)
     if (dtype != 0 || (out_f32 & 1) || ldy != Cout || !use_gemm256(a)) return CDDMSL_ERR_ARG;
     a.y8 = (char*)y8; a.q8 = q8; a.amax8 = (unsigned*)amax8;
