@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash scratch_env_ab.sh VAR v1 v2 ...   -- the bench under VAR=v for each v, twice round-robin
+# usage (GPU box, from the repo root): [EXTRA="--dtype fp8"] bash tools/ab_env.sh VAR v1 v2 ...   -- the bench under VAR=v for each v, twice round-robin
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 VAR=$1; shift
 for rep in 1 2 3; do for v in "$@"; do env $VAR=$v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-forward-roofline ${EXTRA} > gpurun_out/env_${v}_$rep.json 2>> gpurun_out/env.err; done; done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash scratch_ab.sh "<extra hipcc flags>" <tag>  -- rebuilds gemm_conv.o with the flags, relinks the library, runs the bench
+# usage (GPU box, from the repo root): [SRC=roi_align] bash tools/ab_rebuild.sh "<extra hipcc flags>" <tag>  -- bench, rebuild one object with the flags, relinks the library, runs the bench
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
