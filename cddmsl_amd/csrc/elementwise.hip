@@ -10,6 +10,7 @@
 //   sgd_clip        per-parameter grad-norm clip + SGD detectron2/solver/build.py:59-67,104,113-130
 // All kernels read/write 16 B per lane where the layout allows (channels contiguous).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -583,7 +584,12 @@ __global__ void k_sgd(SgdBatch b, const float* norms, float lr, float momentum, 
   }
 }
 
-inline unsigned gsz(long n, int per = 256, long cap = 8192) {
+inline unsigned gsz(long n, int per = 256, long cap = -1) {
+  // default cap on the grid of the grid-stride streaming kernels.  tools/hbm_probe.hip: a plain 16-bytes-per-thread copy runs 6.3 TB/s as a
+  // ONE-SHOT grid (what ATen's elementwise kernels do) against 4.8-5.0 with 8-32 blocks per CU looping; on these kernels (more index
+  // arithmetic per element) 65536 blocks instead of 8192: avgpool2_bwd 1.02 -> 0.89, avgpool2_fwd 1.29 -> 1.25, relu_bwd 0.31 -> 0.29 ms/step
+  static const long env_cap = getenv("CDDMSL_GRID_CAP") ? atol(getenv("CDDMSL_GRID_CAP")) : 65536;
+  if (cap < 0) cap = env_cap;
   long g = (n + per - 1) / per;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }

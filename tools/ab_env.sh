@@ -9,5 +9,5 @@ for v in sys.argv[1:]:
     for rep in (1, 2, 3):
         d = json.loads([l for l in open("gpurun_out/env_%s_%d.json" % (v, rep)) if l.startswith("{")][-1])
         k = d["kernels_ms_per_step"]
-        print("$VAR", v, rep, round(d["value"], 2), round(d["ms_per_step"], 2), "fwd256", k.get("k_conv_fwd256"), "gate", (d.get("losses_gate") or {}).get("ok"))
+        print("$VAR", v, rep, round(d["value"], 2), round(d["ms_per_step"], 2), "fwd256", k.get("k_conv_fwd256"), "avgf", k.get("avgpool2_fwd"), "avgb", k.get("avgpool2_bwd"), "tok", k.get("attn_tokens_fwd"), "relu", k.get("relu_bwd"), "gate", (d.get("losses_gate") or {}).get("ok"))
 PY
