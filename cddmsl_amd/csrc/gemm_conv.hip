@@ -1989,6 +1989,8 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)(ybytes > 0x7fffffffL ? 0x7fffffffL : ybytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, p.relu_mask ? (int)(mbytes > 0x7fffffffL ? 0x7fffffffL : mbytes) : 0, 0x00020000);
   const float relu_floor = p.relu ? 0.f : -__builtin_inff();
+  __shared__ __attribute__((aligned(16))) u32x4 ost[ES == 2 ? 4 * 32 * NT * 4 : 1];    // per wave: one output tile, 32 rows x NT * 64 bytes
+  const bool ost_ok = !p.relu_mask && p.ldy == NT * 32 && (long)p.M * NT * 64 < 0x7fffffffL;
   for (int tile = wave; tile < ntiles; tile += nwaves) {
     const int m = tile * 32 + r;
     const bool vm = m < p.M;
@@ -2036,6 +2038,28 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
         if (WLDS) Mma<T>::step(acc[nt], a[ks], wl[(nt * KS + ks) * 64 + wlane]);
         else Mma<T>::step(acc[nt], a[ks], bw[WLDS ? 0 : nt][WLDS ? 0 : ks]);
       }
+    // bf16 rows of exactly the tile's NT * 32 channels, no mask (every forward launch of the stem / layer1): the tile is 32 * NT * 64
+    // contiguous bytes of y.  It goes through this wave's LDS slot (2-byte writes in the accumulator layout, 16-byte reads in memory
+    // order; one wave's DS operations execute in order, no barrier) and leaves as 2 * NT wave-wide 1 KiB stores instead of 16 * NT
+    // stores of 2 bytes per lane (two 64-byte pieces per instruction).
+    if (ES == 2 && ost_ok) {
+      char* ob = (char*)ost + (threadIdx.x >> 6) * (32 * NT * 64);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int row = (g & 3) + 8 * (g >> 2) + 4 * hh;
+          float v = affine<T>(acc[nt][g], sc[nt], bi[nt]);
+          asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "s"(relu_floor));
+          *(unsigned short*)(ob + row * (NT * 64) + (nt * 32 + r) * 2) = f2bf(v);
+        }
+#pragma unroll
+      for (int i = 0; i < 2 * NT; ++i) {
+        const u32x4 o = *(const u32x4*)(ob + (i * 64 + lane) * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, (unsigned)((i * 64 + lane) * 16), tile * (32 * NT * 64), 0);   // (rows past M: outside num_records)
+      }
+      continue;
+    }
     // element (row (g&3) + 8(g>>2) + 4hh of the tile, channel 32 nt + r): lane offset once, the row in soffset
     const unsigned vy = (unsigned)(((tile * 32 + 4 * hh) * p.ldy + r) * ES), vmk = (unsigned)(((tile * 32 + 4 * hh) * p.ldm + r) * ES);
 #pragma unroll
