@@ -72,19 +72,24 @@ def test_device_batches_stage_through_one_pinned_copy(tmp_path):
         next(it)
 
 
-@pytest.mark.parametrize("workers", [0, 2])
-def test_multi_scale_training_on_the_real_loader_keeps_the_allocator_flat(tmp_path, workers):
+@pytest.mark.parametrize("workers,dtype", [(0, "bf16"), (2, "bf16"), (0, "fp8")])
+def test_multi_scale_training_on_the_real_loader_keeps_the_allocator_flat(tmp_path, monkeypatch, workers, dtype):
     """SURVEY.md 8(f)2 / data/build.py:262-308: the paired VOC loader with INPUT.MIN_SIZE_TRAIN multi-scale sampling feeds the
     full step (all three branches) for 24 iterations -- every batch another shape through the kernel dispatch, the workspace
     registry and the gradient buckets -- without an error, with finite losses, and without the caching allocator growing after
-    iteration 10 by more than the largest batch's share (shapes seen late may still be larger than any before)."""
+    iteration 10 by more than the largest batch's share (shapes seen late may still be larger than any before).  The fp8 case forces
+    every e4m3 kernel on at this size (forward, input- and weight-gradient GEMMs, delayed-scaling slots, the copies kept for backward):
+    their shapes change every iteration too, and ``_write_metrics`` reads the quantisers' non-finite flag each step."""
+    if dtype == "fp8":
+        monkeypatch.setenv("CDDMSL_FP8_MIN_TILES", "1")
+        monkeypatch.setenv("CDDMSL_FP8_WGRAD_MIN_M", "1")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench
     import loader_bench
     from cddmsl_amd import data, engine, synthetic
     from cddmsl_amd.evaluation import VOC_CLASS_NAMES
     base = loader_bench.make_voc_tree(str(tmp_path), 24)
-    cfg = bench.make_cfg("bf16")
+    cfg = bench.make_cfg(dtype)
     cfg.merge_from_list(["MODEL.DEVICE", "cuda:0", "INPUT.MIN_SIZE_TRAIN", (224, 256, 288, 320), "INPUT.MAX_SIZE_TRAIN", 448,
                          "MODEL.RPN.PRE_NMS_TOPK_TRAIN", 2000, "MODEL.RPN.POST_NMS_TOPK_TRAIN", 500, "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", 128])
     dicts = data.load_voc_instances(base, "trainval", VOC_CLASS_NAMES, dt_data="clipart")
