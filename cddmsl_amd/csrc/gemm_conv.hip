@@ -1944,9 +1944,10 @@ __global__ __launch_bounds__(256) void k_weight_prep_multi(const long long* tabl
 // L1/L2).  All loads of a tile are issued before its MFMAs.  Output: lanes = consecutive channels (64 contiguous bytes
 // per pixel and tile).  Same accumulation order as k_conv_fwd (chunk pairs in K order) -> bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int CPP, int NT>
+template <typename T, int CPP, int NT, int NTAP = 9>     // NTAP = 1: the same streaming structure for a 1x1 layer with 32 / 64 output channels
 __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
-  constexpr int KC = 9 * CPP, KS = (KC + 1) / 2;       // 16-byte chunks of a weight row; k-steps of two chunks
+  constexpr int KC = NTAP * CPP, KS = (KC + 1) / 2;    // 16-byte chunks of a weight row; k-steps of two chunks
+  constexpr int PAD = NTAP == 9 ? 1 : 0;
   constexpr int ES = Mma<T>::ES;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   // weights as MFMA B fragments: fragment (nt, ks) of a lane = chunk 2ks+hh of weight row nt*32 + r (zero past the row end).
@@ -1997,15 +1998,17 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(ConvArgs p) {
     const unsigned mm = vm ? m : 0;
     const unsigned tq = fdiv(mm, p.dWo), ox = mm - tq * p.Wo;
     const unsigned img = fdiv(tq, p.dHo), oy = tq - img * p.Ho;
-    const int iy0 = (int)oy * p.stride - 1, ix0 = (int)ox * p.stride - 1;
+    const int iy0 = (int)oy * p.stride - PAD, ix0 = (int)ox * p.stride - PAD;
     // byte offset of tap (0,0), chunk 0 of this lane's pixel (may be "negative": wraps, and is then masked by the tap test)
     const unsigned lbase = (unsigned)((((int)img * p.Hi + iy0 + 1) * p.Wi + ix0 + 1) * (CPP * 16)) + (CPP > 1 ? hh * 16 : 0);
     unsigned bad = vm ? 0u : 0x1ffu;                // bit (3 ky + kx): that tap of this pixel is outside the image
+    if (NTAP == 9) {
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-        if ((unsigned)(iy0 + ky) >= (unsigned)p.Hi || (unsigned)(ix0 + kx) >= (unsigned)p.Wi) bad |= 1u << (3 * ky + kx);
+        for (int kx = 0; kx < 3; ++kx)
+          if ((unsigned)(iy0 + ky) >= (unsigned)p.Hi || (unsigned)(ix0 + kx) >= (unsigned)p.Wi) bad |= 1u << (3 * ky + kx);
+    }
     u32x4 a[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -3012,6 +3015,17 @@ template <typename T> int conv_fwd_launch(ConvArgs& a, hipStream_t st) {
     else if (a.cpp == 8) hipLaunchKernelGGL((k_conv3x3_small<T, 8, 2>), dim3(nb), dim3(256), 0, st, a);
     else if (a.Cout == 32) hipLaunchKernelGGL((k_conv3x3_small<T, 4, 1>), dim3(nb), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv3x3_small<T, 4, 2>), dim3(nb), dim3(256), 0, st, a);
+    return launch_status();
+  }
+  // ... and the 1x1 layers of res2 with 64 output channels (64 -> 64, 256 -> 64: one 128-column tile of the GEMM kernels would be half
+  // empty): the same kernel with one tap, bf16.  CDDMSL_SMALL_1X1=0: the 128x128 GEMM kernel (A/B)
+  if (sizeof(T) == 2 && !a.pool && a.KH == 1 && a.KW == 1 && a.pad == 0 && a.stride == 1 && a.Cout == 64 && (a.cpp == 8 || a.cpp == 32) &&
+      !a.residual && !a.out_f32 && !a.y8 && g_batch == 1 && a.xrs == a.cpp && a.wrs == a.Kc && a.ldy == 64 &&
+      !(getenv("CDDMSL_SMALL_1X1") && atoi(getenv("CDDMSL_SMALL_1X1")) == 0)) {
+    g_last_kernel = 8;
+    if (g_plan_only) return CDDMSL_OK;
+    if (a.cpp == 8) hipLaunchKernelGGL((k_conv3x3_small<T, 8, 2, 1>), dim3(512), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv3x3_small<T, 32, 2, 1>), dim3(512), dim3(256), 0, st, a);
     return launch_status();
   }
   if (use_fwd2(a)) {

@@ -513,3 +513,26 @@ def test_conv3x3_small_channel_streaming_kernel(case, dtype, tol):
     assert hip._L().cddmsl_last_kernel() == 8
     err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max()
     assert err < tol, float(err)
+
+
+@pytest.mark.parametrize("case", [(2, 37, 53, 256, 64), (1, 50, 83, 64, 64), (3, 5, 7, 256, 64)])
+def test_conv1x1_to_64_channels_on_the_streaming_kernel(case, monkeypatch):
+    """res2's 1x1 layers with 64 output channels (64 -> 64, 256 -> 64; clip_backbone.py:57-70) run on the streaming kernel's one-tap
+    instantiation (a 128-column GEMM tile would be half empty): vs ATen fp32 with the FrozenBN + ReLU epilogue, ragged tile counts, and
+    bit-equal to the GEMM kernel it replaces (same products, same k order inside an MFMA step; CDDMSL_SMALL_1X1=0 selects it)."""
+    from cddmsl_amd import hip
+    N, H, W, Cin, Cout = case
+    x = _rand((N, H, W, Cin), 51).bfloat16()
+    w = (_rand((Cout, 1, 1, Cin), 52) * Cin ** -0.5)
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(53)) + 0.5
+    bias = _rand((Cout,), 54, 0.1)
+    wf, _ = hip.weight_prep(w.cuda(), None, torch.bfloat16, True, False)
+    y = hip.conv_fwd(x.cuda(), wf, scale.cuda(), bias.cuda(), relu=True)
+    assert hip._L().cddmsl_last_kernel() == 8
+    ref = F.relu(x.float().view(-1, Cin) @ wf.float().cpu().view(Cout, Cin).t() * scale + bias).view(N, H, W, Cout)
+    err = (y.float().cpu() - ref).abs().max() / ref.abs().max()
+    assert err < 6e-3, float(err)
+    monkeypatch.setenv("CDDMSL_SMALL_1X1", "0")
+    y0 = hip.conv_fwd(x.cuda(), wf, scale.cuda(), bias.cuda(), relu=True)
+    assert hip._L().cddmsl_last_kernel() != 8
+    assert float((y.float() - y0.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
