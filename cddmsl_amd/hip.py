@@ -34,6 +34,8 @@ def _L():
         L.cddmsl_meanpool_fwd.argtypes = [vp, vp, c_long, ci, ci, ci, vp]
         L.cddmsl_meanpool_bwd.argtypes = [vp, vp, c_long, ci, ci, ci, vp]
         L.cddmsl_preprocess224.argtypes = [vp, vp] + [ci] * 11 + [vp, vp, ci, vp]
+        L.cddmsl_preprocess_batch.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp, vp, ci, ci, vp]
+        L.cddmsl_preprocess224_batch.argtypes = [vp, vp, vp, ci, vp] + [ci] * 8 + [vp, vp, ci, vp]
         L.cddmsl_avgpool2_fwd.argtypes = [vp, vp] + [ci] * 5 + [vp]
         L.cddmsl_avgpool2_bwd.argtypes = [vp] * 4 + [ci] * 5 + [vp]
         L.cddmsl_avgpool2_bwd_q8.argtypes = [vp] * 4 + [ci] * 4 + [vp] * 4
@@ -452,6 +454,16 @@ def _f3(v):
     return (c_float * 3)(*[float(x) for x in v])
 
 
+def _image_table(images_u8):
+    """host arrays (device pointers, heights, widths) of a list of CHW images: the batched preprocessing entries' image table"""
+    import ctypes
+    n = len(images_u8)
+    ptrs = (ctypes.c_void_p * n)(*[im.data_ptr() for im in images_u8])
+    hs = (ctypes.c_int * n)(*[int(im.shape[1]) for im in images_u8])
+    ws = (ctypes.c_int * n)(*[int(im.shape[2]) for im in images_u8])
+    return ptrs, hs, ws
+
+
 @_timed("preprocess")
 def preprocess(images_u8, Hp, Wp, mean, std, dtype, Cp=None, div255=True):
     """list of u8 CHW device tensors -> normalised, zero-padded NHWC [N,Hp,Wp,Cp] (rcnn.py:758-768).
@@ -460,10 +472,11 @@ def preprocess(images_u8, Hp, Wp, mean, std, dtype, Cp=None, div255=True):
     Cp = Cp or (8 if dtype == torch.bfloat16 else 4)
     out = torch.empty((len(images_u8), Hp, Wp, Cp), device=images_u8[0].device, dtype=dtype)
     m, s = _f3(mean), _f3(std)
-    for n, im in enumerate(images_u8):
+    for im in images_u8:
         assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[0] == 3 and im.is_contiguous()
-        check(_L().cddmsl_preprocess(ptr(im), ptr(out), n, im.shape[1], im.shape[2], Hp, Wp, Cp, m, s, int(div255), DT[dtype], stream_ptr()),
-              "cddmsl_preprocess")
+    ptrs, hs, ws = _image_table(images_u8)
+    check(_L().cddmsl_preprocess_batch(ptrs, hs, ws, len(images_u8), ptr(out), Hp, Wp, Cp, m, s, int(div255), DT[dtype], stream_ptr()),
+          "cddmsl_preprocess_batch")
     return out
 
 
@@ -479,10 +492,11 @@ def preprocess224(images_u8, Hp, Wp, mean, std, dtype, size=224, Cp=None):
     top, left = int(round((RH - size) / 2.0)), int(round((RW - size) / 2.0))
     out = torch.empty((len(images_u8), size, size, Cp), device=images_u8[0].device, dtype=dtype)
     m, s = _f3(mean), _f3(std)
-    for n, im in enumerate(images_u8):
-        assert im.dtype == torch.uint8 and im.is_contiguous()
-        check(_L().cddmsl_preprocess224(ptr(im), ptr(out), n, im.shape[1], im.shape[2], Hp, Wp, RH, RW, top, left, size, Cp,
-                                         m, s, DT[dtype], stream_ptr()), "cddmsl_preprocess224")
+    for im in images_u8:
+        assert im.dtype == torch.uint8 and im.dim() == 3 and im.is_contiguous()
+    ptrs, hs, ws = _image_table(images_u8)
+    check(_L().cddmsl_preprocess224_batch(ptrs, hs, ws, len(images_u8), ptr(out), Hp, Wp, RH, RW, top, left, size, Cp,
+                                           m, s, DT[dtype], stream_ptr()), "cddmsl_preprocess224_batch")
     return out
 
 

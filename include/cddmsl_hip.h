@@ -249,6 +249,12 @@ int cddmsl_preprocess(const unsigned char* img, void* out, int n, int h, int w, 
                       const float* std3, int div255, int dtype, void* stream);
 int cddmsl_preprocess224(const unsigned char* img, void* out, int n, int h, int w, int Hp, int Wp, int RH, int RW, int top,
                          int left, int S, int Cp, const float* mean3, const float* std3, int dtype, void* stream);
+/* the same two for a whole batch in one launch: imgs / hs / ws are HOST arrays of N device pointers / heights / widths (the images are
+ * separate tensors of different sizes: ImageList.from_tensors, structures/image_list.py:72-124); image j is written to out[j] */
+int cddmsl_preprocess_batch(const unsigned char* const* imgs, const int* hs, const int* ws, int N, void* out, int Hp, int Wp, int Cp,
+                            const float* mean3, const float* std3, int div255, int dtype, void* stream);
+int cddmsl_preprocess224_batch(const unsigned char* const* imgs, const int* hs, const int* ws, int N, void* out, int Hp, int Wp, int RH,
+                               int RW, int top, int left, int S, int Cp, const float* mean3, const float* std3, int dtype, void* stream);
 int cddmsl_avgpool2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
 int cddmsl_avgpool2_bwd(const void* dy, const void* mask, const void* add, void* dx, int N, int H, int W, int C, int dtype,
                         void* stream);

@@ -95,6 +95,23 @@ def test_preprocess(dtype, tol):
     out2 = hip.preprocess224([i.cuda() for i in imgs2], 260, 330, cfg.pixel_mean, cfg.pixel_std, dtype)
     assert out2.shape[:3] == (2, 224, 224)
     assert (out2[..., :3].float().cpu().permute(0, 3, 1, 2) - ref2).abs().max() < max(tol * 5, 2e-5)
+    # the per-image entry points of the C-ABI (one launch per image) write the same bytes as the batched ones, and a batch larger than
+    # one launch's image table (32) is split correctly
+    from cddmsl_amd.hip import _L, _f3, DT, ptr, stream_ptr
+    cu = [i.cuda() for i in imgs]
+    one = torch.empty_like(out)
+    m, sd = _f3(cfg.pixel_mean), _f3(cfg.pixel_std)
+    for n, im in enumerate(cu):
+        assert _L().cddmsl_preprocess(ptr(im), ptr(one), n, im.shape[1], im.shape[2], 41, 53, out.shape[-1], m, sd, 1, DT[dtype], stream_ptr()) == 0
+    assert torch.equal(one, out)
+    cu2 = [i.cuda() for i in imgs2]
+    one2 = torch.empty_like(out2)
+    for n, im in enumerate(cu2):
+        assert _L().cddmsl_preprocess224(ptr(im), ptr(one2), n, im.shape[1], im.shape[2], 260, 330, 224, int(224 * 330 / 260), 0,
+                                         int(round((int(224 * 330 / 260) - 224) / 2.0)), 224, out2.shape[-1], m, sd, DT[dtype], stream_ptr()) == 0
+    assert torch.equal(one2, out2)
+    many = hip.preprocess(cu * 20, 41, 53, cfg.pixel_mean, cfg.pixel_std, dtype)           # 40 images: two launches
+    assert torch.equal(many, out.repeat(20, 1, 1, 1))
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
