@@ -96,6 +96,27 @@ def test_conv_wgrad_fp8_is_the_f32_product_of_the_dequantised_operands(case):
     assert err <= 2e-5 * ref + 2e-4 * pmax, (case, err, ref, pmax)
 
 
+def test_conv_wgrad_fp8_rejects_what_it_does_not_take():
+    """shapes outside the kernel's contract are refused (CDDMSL_ERR_ARG = 1), not computed wrongly; an empty batch is a no-op"""
+    from cddmsl_amd import hip
+    from cddmsl_amd.hip import _L, ptr, stream_ptr
+    x8 = torch.zeros(2, 6, 6, 256, dtype=torch.uint8, device="cuda")
+    d8 = torch.zeros(2, 6, 6, 256, dtype=torch.uint8, device="cuda")
+    dw = torch.zeros(256, 3, 3, 256, device="cuda")
+    sc = torch.ones(256, device="cuda")
+    L = _L()
+    ok = lambda Cin, Cout, KH, KW, pad, ldd: L.cddmsl_conv_wgrad_fp8_ok(Cin, Cout, KH, KW, pad, ldd)
+    assert ok(256, 256, 3, 3, 1, 256) == 1 and ok(512, 2048, 1, 1, 0, 2048) == 1
+    assert ok(128, 256, 3, 3, 1, 256) == 0 and ok(256, 128, 3, 3, 1, 128) == 0 and ok(256, 256, 3, 3, 0, 256) == 0 and ok(256, 256, 3, 1, 1, 256) == 0
+    call = lambda N, Cin, Cout, KH, pad, ldd: L.cddmsl_conv_wgrad_fp8(ptr(x8), ptr(d8), ptr(dw), ptr(sc), N, 6, 6, Cin, Cout, KH, KH, pad, ldd, stream_ptr())
+    assert call(2, 128, 256, 3, 1, 256) == 1 and call(2, 256, 256, 3, 0, 256) == 1 and call(2, 256, 256, 3, 1, 128) == 1 and call(-1, 256, 256, 3, 1, 256) == 1
+    assert call(0, 256, 256, 3, 1, 256) == 0 and float(dw.abs().max()) == 0.0
+    assert call(2, 256, 256, 3, 1, 256) == 0
+    torch.cuda.synchronize()
+    assert float(dw.abs().max()) == 0.0                 # zeros in, zeros out
+    assert not hip.conv_wgrad_fp8_ok(10 ** 6, 256, 256, 1, 1, 0) and hip.conv_wgrad_fp8_ok(10 ** 6, 256, 256, 1, 1, 0, None, False)
+
+
 def test_avgpool2_bwd_with_e4m3_second_output():
     """AvgPool2d(2) backward (+ ReLU mask) writing the e4m3 copy of its result in the same pass: the bf16 result is the plain
     kernel's, the copy is the quantiser's on the f32 value (<= 1 code from quantising the bf16 result), the maximum is recorded."""
