@@ -61,13 +61,26 @@ __device__ __forceinline__ float half_max(float v) {
   return v;
 }
 
-// global [t rows][96 cols] (row stride ld elements) -> LDS image, rows t..95 zeroed
-__device__ __forceinline__ void stage(char* img, const char* g, int t, int ld, int tid) {
-  for (int c = tid; c < AT * 12; c += 192) {
-    const int row = c / 12, ch = c - row * 12;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (row < t) v = *(const u32x4*)(g + ((long)row * ld) * 2 + ch * 16);
-    *(u32x4*)(img + row * ARS + ch * 16) = v;
+// global [t rows][96 cols] (row stride ld elements) -> LDS image, rows t..95 zeroed.  In two steps, so that a kernel can REQUEST every
+// chunk of all its images before it waits for the first: written as one loop (load, LDS write, next chunk) hipcc kept the loop and
+// put s_waitcnt vmcnt(0) in front of every write -- 6 (forward) / 18 (backward) serialised memory round trips per workgroup, most of
+// its lifetime at two workgroups per CU (found in the ISA; the backward kernel went 236 -> ~100 us per launch).
+__device__ __forceinline__ void stage_load(u32x4 (&v)[6], const char* g, int t, int ld, int tid) {
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {                 // 96 rows x 12 chunks = 6 per thread of the 192
+    const int c = tid + it * 192, row = c / 12, ch = c - row * 12;
+    // (branch-free: a padding row reads the last valid row and is zeroed afterwards -- under `if (row < t)` hipcc put a wait behind
+    // every load of the forward kernel)
+    const u32x4 x = *(const u32x4*)(g + ((long)(row < t ? row : t - 1) * ld) * 2 + ch * 16);
+    const unsigned keep = row < t ? 0xffffffffu : 0u;
+    v[it] = u32x4{x[0] & keep, x[1] & keep, x[2] & keep, x[3] & keep};
+  }
+}
+__device__ __forceinline__ void stage_store(char* img, const u32x4 (&v)[6], int tid) {
+#pragma unroll
+  for (int it = 0; it < 6; ++it) {
+    const int c = tid + it * 192, row = c / 12, ch = c - row * 12;
+    *(u32x4*)(img + row * ARS + ch * 16) = v[it];
   }
 }
 // C tile (32 x 32, rows row0.., cols col0..) -> bf16 image
@@ -168,13 +181,21 @@ __global__ __launch_bounds__(192) void k_attn_small_fwd(AttnArgs p) {
   const char* qg = p.q + (row0 * p.ldq + h * AT) * 2;
   const char* kg = p.k + (row0 * p.ldk + h * AT) * 2;
   u32x4 qf[6], kf[3][6];
+  {
+    // V's six chunks in one round trip, written to LDS before the Q / K fragments are requested: with all 30 loads in flight at once
+    // the kernel needed 200 registers (24 + 96 of data, 60 of addresses) and lost two of its four workgroups per CU (89 -> 100 us
+    // per launch); as two round trips it keeps them
+    u32x4 sv[6];
+    stage_load(sv, p.v + (row0 * p.ldv + h * AT) * 2, p.t, p.ldv, tid);
+    stage_store(Vi, sv, tid);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int kk = 0; kk < 6; ++kk) qf[kk] = gfrag_cols(qg, p.ldq, p.t, i0, kk, lane);
 #pragma unroll
   for (int jt = 0; jt < 3; ++jt)
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) kf[jt][kk] = gfrag_cols(kg, p.ldk, p.t, jt * 32, kk, lane);
-  stage(Vi, p.v + (row0 * p.ldv + h * AT) * 2, p.t, p.ldv, tid);
   f32x16 P[3];
   scores_softmax_regs(qf, kf, p.t, p.scale, lane, P);
 #pragma unroll
@@ -210,9 +231,15 @@ __global__ __launch_bounds__(192, 2) void k_attn_small_bwd(AttnArgs p) {
   for (int jt = 0; jt < 3; ++jt)
 #pragma unroll
     for (int kk = 0; kk < 6; ++kk) vf[jt][kk] = gfrag_cols(vg, p.ldv, p.t, jt * 32, kk, lane);
-  stage(Qi, p.q + (row0 * p.ldq + h * AT) * 2, p.t, p.ldq, tid);
-  stage(Ki, p.k + (row0 * p.ldk + h * AT) * 2, p.t, p.ldk, tid);
-  stage(Di, p.dout + (row0 * p.ldo + h * AT) * 2, p.t, p.ldo, tid);
+  {
+    u32x4 sq[6], sk[6], sd[6];
+    stage_load(sq, p.q + (row0 * p.ldq + h * AT) * 2, p.t, p.ldq, tid);
+    stage_load(sk, p.k + (row0 * p.ldk + h * AT) * 2, p.t, p.ldk, tid);
+    stage_load(sd, p.dout + (row0 * p.ldo + h * AT) * 2, p.t, p.ldo, tid);
+    stage_store(Qi, sq, tid);
+    stage_store(Ki, sk, tid);
+    stage_store(Di, sd, tid);
+  }
   __syncthreads();
   f32x16 P[3], dP[3];
   scores_softmax(Qi, Ki, i0, p.t, p.scale, lane, P);
