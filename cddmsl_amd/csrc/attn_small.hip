@@ -50,15 +50,23 @@ __device__ __forceinline__ u32x4 gfrag_cols(const char* g, int ld, int t, int ro
 __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
 }
-__device__ __forceinline__ float half_sum(float v) {   // over the 32 lanes that share lane>>5
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// All-reduce over the 32 lanes that share lane>>5.  __shfl_xor lowers to ds_bpermute_b32 -- an LDS round trip per step, 5 per
+// reduction, 240 in the backward kernel, each behind an s_waitcnt -- so the steps inside a 16-lane row are DPP moves (vector ALU, no
+// wait: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror; once every lane of a group holds the group's value the
+// mirrors pair whole groups) and only the last one crosses rows: ds_swizzle, bit mode, lane ^ 16.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float swz16(float v) {     // the value of lane ^ 16 (and_mask 0x1f, or_mask 0, xor_mask 0x10)
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+  return v + swz16(v);
 }
 __device__ __forceinline__ float half_max(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+  return fmaxf(v, swz16(v));
 }
 
 // global [t rows][96 cols] (row stride ld elements) -> LDS image, rows t..95 zeroed.  In two steps, so that a kernel can REQUEST every
