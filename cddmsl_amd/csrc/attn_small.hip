@@ -123,11 +123,15 @@ __device__ __forceinline__ void rows_out(const char* img, char* gp, int ld, int 
 // S = scale * Q K^T for this wave's 32 query rows, masked softmax over the t valid columns -> P (f32, C layout)
 __device__ __forceinline__ void scores_softmax(const char* Qi, const char* Ki, int i0, int t, float scale, int lane, f32x16 (&P)[3]) {
 #pragma unroll
-  for (int jt = 0; jt < 3; ++jt) {
+  for (int jt = 0; jt < 3; ++jt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) P[jt][r] = 0.f;
+  // (k-step outer, column tile inner: three independent accumulation chains in flight instead of six dependent MFMAs in a row)
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) mma(P[jt], frag_cols(Qi, i0, kk, lane), frag_cols(Ki, jt * 32, kk, lane));
+  for (int kk = 0; kk < 6; ++kk) {
+    const u32x4 qa = frag_cols(Qi, i0, kk, lane);
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) mma(P[jt], qa, frag_cols(Ki, jt * 32, kk, lane));
   }
   const int c = lane & 31;
 #pragma unroll
@@ -153,12 +157,13 @@ __device__ __forceinline__ void scores_softmax(const char* Qi, const char* Ki, i
 // its columns needs no LDS image)
 __device__ __forceinline__ void scores_softmax_regs(const u32x4 (&qf)[6], const u32x4 (&kf)[3][6], int t, float scale, int lane, f32x16 (&P)[3]) {
 #pragma unroll
-  for (int jt = 0; jt < 3; ++jt) {
+  for (int jt = 0; jt < 3; ++jt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) P[jt][r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) mma(P[jt], qf[kk], kf[jt][kk]);
-  }
+  for (int kk = 0; kk < 6; ++kk)
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) mma(P[jt], qf[kk], kf[jt][kk]);
   const int c = lane & 31;
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -212,11 +217,14 @@ __global__ __launch_bounds__(192) void k_attn_small_fwd(AttnArgs p) {
   char* op = p.o + (row0 * p.ldo + h * AT) * 2;
   f32x16 acc[3];
 #pragma unroll
-  for (int ct = 0; ct < 3; ++ct) {
+  for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) mma(acc[ct], frag_cols(Pi, i0, kk, lane), frag_rows(Vi, ct * 32, kk, lane));
+  for (int kk = 0; kk < 6; ++kk) {
+    const u32x4 pa = frag_cols(Pi, i0, kk, lane);
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) mma(acc[ct], pa, frag_rows(Vi, ct * 32, kk, lane));
   }
   // O goes out through this wave's own rows of the P image (no longer needed): whole 16-byte chunks per lane
 #pragma unroll
@@ -252,11 +260,14 @@ __global__ __launch_bounds__(192, 2) void k_attn_small_bwd(AttnArgs p) {
   f32x16 P[3], dP[3];
   scores_softmax(Qi, Ki, i0, p.t, p.scale, lane, P);
 #pragma unroll
-  for (int jt = 0; jt < 3; ++jt) {
+  for (int jt = 0; jt < 3; ++jt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dP[jt][r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) mma(dP[jt], frag_cols(Di, i0, kk, lane), vf[jt][kk]);
+  for (int kk = 0; kk < 6; ++kk) {
+    const u32x4 da = frag_cols(Di, i0, kk, lane);
+#pragma unroll
+    for (int jt = 0; jt < 3; ++jt) mma(dP[jt], da, vf[jt][kk]);
   }
 #pragma unroll
   for (int g = 0; g < 16; ++g) {
@@ -275,11 +286,14 @@ __global__ __launch_bounds__(192, 2) void k_attn_small_bwd(AttnArgs p) {
   char* dvp = p.dv + (row0 * p.ldv + h * AT) * 2;
   f32x16 av[3];
 #pragma unroll
-  for (int ct = 0; ct < 3; ++ct) {
+  for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) av[ct][r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) mma(av[ct], frag_rows(Xi, i0, kk, lane), frag_rows(Di, ct * 32, kk, lane));   // dV[j] = sum_i P[i][j] dO[i]   (j0 = i0)
+  for (int kk = 0; kk < 6; ++kk) {
+    const u32x4 pa = frag_rows(Xi, i0, kk, lane);
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) mma(av[ct], pa, frag_rows(Di, ct * 32, kk, lane));   // dV[j] = sum_i P[i][j] dO[i]   (j0 = i0)
   }
   __syncthreads();                                  // every wave is done reading P (the image now takes dS) and dO
   // dV leaves right away through the dO image (dead from here on; own rows): its 48 accumulators are free before dQ / dK
@@ -292,13 +306,16 @@ __global__ __launch_bounds__(192, 2) void k_attn_small_bwd(AttnArgs p) {
   __syncthreads();
   f32x16 aq[3], ak[3];
 #pragma unroll
-  for (int ct = 0; ct < 3; ++ct) {
+  for (int ct = 0; ct < 3; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { aq[ct][r] = 0.f; ak[ct][r] = 0.f; }
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) {
-      mma(aq[ct], frag_cols(Xi, i0, kk, lane), frag_rows(Ki, ct * 32, kk, lane));     // dQ[i] = sum_j dS[i][j] K[j]
-      mma(ak[ct], frag_rows(Xi, i0, kk, lane), frag_rows(Qi, ct * 32, kk, lane));     // dK[j] = sum_i dS[i][j] Q[i]
+  for (int kk = 0; kk < 6; ++kk) {
+    const u32x4 sc_ = frag_cols(Xi, i0, kk, lane), sr_ = frag_rows(Xi, i0, kk, lane);    // (read once per k-step, not once per column tile)
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+      mma(aq[ct], sc_, frag_rows(Ki, ct * 32, kk, lane));     // dQ[i] = sum_j dS[i][j] K[j]
+      mma(ak[ct], sr_, frag_rows(Qi, ct * 32, kk, lane));     // dK[j] = sum_i dS[i][j] Q[i]
     }
   }
   __syncthreads();                                  // all reads of Q, K, dO done: their images carry the results out (own rows)
