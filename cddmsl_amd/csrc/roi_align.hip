@@ -495,9 +495,20 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(const char* dy, const flo
     for (int q4 = 0; q4 < TS * TS; ++q4)
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[u][q4][q] = 0.f;
-  for (int k = k0; k < k1; ++k) {
-    const int* f = fp + 4 * k;
-    if (py0 + TS - 1 < f[0] || py0 > f[1] || px0 + TS - 1 < f[2] || px0 > f[3]) continue;   // uniform across the block
+  // The image's RoIs are tested against the tile 64 at a time -- lane l takes RoI kb + l's footprint, a ballot gives the ones that reach
+  // the tile (the same mask in every wave of the block) -- instead of one scalar load + wait + branch per RoI (512 of them per tile, a
+  // fifth of the kernel's time); the hits are then visited in ascending order, as before.
+  const int lane_ = threadIdx.x & 63;
+  for (int kb = k0; kb < k1; kb += 64) {
+    bool hit = false;
+    if (kb + lane_ < k1) {
+      const int* f = fp + 4 * (kb + lane_);
+      hit = !(py0 + TS - 1 < f[0] || py0 > f[1] || px0 + TS - 1 < f[2] || px0 > f[3]);
+    }
+    unsigned long long hits = __ballot(hit);
+  while (hits) {
+    const int k = kb + __builtin_ctzll(hits);
+    hits &= hits - 1;
     const float* ayr = ay + ((long)k * H + py0) * ph;
     const float* axr = ax + ((long)k * W + px0) * pw;
     // Lane l of every wave holds the weights of bin row l / bin column l for the tile's TS pixel rows / columns (2 + 2 loads
@@ -550,6 +561,7 @@ __global__ __launch_bounds__(256) void k_roi_align_bwd(const char* dy, const flo
           }
       }
     }
+  }
   }
 #pragma unroll
   for (int u = 0; u < NC; ++u) {
