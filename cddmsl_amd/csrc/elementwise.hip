@@ -711,7 +711,9 @@ extern "C" int cddmsl_avgpool2_bwd_q8(const void* dy, const void* mask, const vo
   const int cch = C * 2 / 16;
   const long total = (long)N * H * W * cch;
   if (total == 0) return CDDMSL_OK;
-  hipLaunchKernelGGL(k_avgpool2_bwd_q8, dim3(gsz(total)), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)mask, (const char*)add,
+  // (8192 blocks, not the streaming kernels' 65536: every block ends with a reduction and an atomic -- measured 1.17 vs 1.21 ms; the
+  // quantiser itself, same structure, 0.82 vs 1.07 ms at 2048 vs 65536 blocks)
+  hipLaunchKernelGGL(k_avgpool2_bwd_q8, dim3(gsz(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const char*)dy, (const char*)mask, (const char*)add,
                      (char*)dx, N, H, W, cch, (char*)y8, q8, (unsigned*)amax8);
   return launch_status();
 }
