@@ -324,6 +324,20 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(const char* x, const
     s_n[0] = n; s_n[1] = first;
   }
   __syncthreads();
+  // The x tables leave LDS once, spread over the lanes of every wave (entry s in lane s & 63 of register s >> 6), and the walk below reads
+  // them with v_readlane: the former walk took one LDS read (+ readfirstlane) per sample and table, a full LDS latency inside every
+  // iteration of a 28-56-iteration serial loop.  (Loaded by EVERY lane, before the lanes without a channel chunk leave: v_readlane
+  // reads a lane's register whether or not the lane is still active.)
+  const int lane = threadIdx.x & 63;
+  int xlr[ROI_MAXS / 64], xwlr[ROI_MAXS / 64], xwhr[ROI_MAXS / 64];
+#pragma unroll
+  for (int q = 0; q < ROI_MAXS / 64; ++q) {
+    const int idx = q * 64 + lane;
+    const bool in = idx < nx;
+    xlr[q] = in ? s_xl[idx] : -1;
+    xwlr[q] = in ? __builtin_bit_cast(int, s_xwl[idx]) : 0;
+    xwhr[q] = in ? __builtin_bit_cast(int, s_xwh[idx]) : 0;
+  }
   if (c >= cch) return;
   const int nrow = __builtin_amdgcn_readfirstlane(s_n[0]);
   const int first = __builtin_amdgcn_readfirstlane(s_n[1]);
@@ -389,8 +403,11 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(const char* x, const
     return;
   }
   int left = spo, j = 0;
-  for (int s = 0; s < nx; ++s) {
-    const int xl = __builtin_amdgcn_readfirstlane(s_xl[s]);
+#pragma unroll
+  for (int q = 0; q < ROI_MAXS / 64; ++q) {
+  const int lim = min(64, nx - q * 64);
+  for (int l = 0; l < lim; ++l) {
+    const int xl = __builtin_amdgcn_readlane(xlr[q], l);
     if (any && xl >= 0) {
       while (cur < xl) {                                       // slide: x_lo never decreases along the row
         ++cur;
@@ -399,8 +416,8 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(const char* x, const
         if (ahead) { finish(R1); issue(min(cur + 2, W - 1)); }
         else rload(min(cur + 1, W - 1), R1);
       }
-      const float wl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_xwl[s])));
-      const float wh = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_xwh[s])));
+      const float wl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xwlr[q], l));
+      const float wh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xwhr[q], l));
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] = __builtin_fmaf(wl, R0[q], __builtin_fmaf(wh, R1[q], acc[q]));
     }
@@ -417,6 +434,7 @@ __global__ __launch_bounds__(256) void k_roi_align_fwd_rows(const char* x, const
       __builtin_nontemporal_store(Vec<__bf16>::pack(o), &yo[(long)j * cch]);
       ++j; left = spo;
     }
+  }
   }
 }
 
