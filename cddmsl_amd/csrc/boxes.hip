@@ -127,10 +127,18 @@ __global__ __launch_bounds__(256) void k_nms_scan(const unsigned long long* mask
       const unsigned long long d = dnext;         // this chunk's diagonal word, requested one chunk ago (it depends on no decision)
       dnext = (c + 1 < nw && i + 64 < n) ? m[(long)(i + 64) * nw + c + 1] : 0ull;
       const int dlo = (int)(unsigned)d, dhi = (int)(unsigned)(d >> 32);
-      unsigned long long cur = rem[c], km = 0;
+      // the chunk's "removed" word in scalar registers; the walk jumps from one surviving candidate to the next (s_ff1 on the word's
+      // complement) instead of testing all 64 bit positions in turn -- as many iterations as candidates kept, ~10 per chunk, not 64
+      const unsigned long long r0 = rem[c];
+      unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(r0 >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)r0);
+      unsigned long long km = 0, todo = ~0ull;
       const int cnt0 = cnt;
-      for (int b = 0; b < 64 && cnt < max_keep; ++b) {
-        if ((cur >> b) & 1ull) continue;
+      while (cnt < max_keep) {
+        const unsigned long long a = ~cur & todo;
+        if (!a) break;
+        const int b = __builtin_ctzll(a);
+        todo = b == 63 ? 0ull : (~0ull << (b + 1));
         km |= 1ull << b;
         ++cnt;
         cur |= ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, b) << 32) | (unsigned)__builtin_amdgcn_readlane(dlo, b);
