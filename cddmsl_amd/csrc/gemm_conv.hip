@@ -3057,6 +3057,14 @@ extern "C" void cddmsl_debug_tile_stamps(unsigned long long* p) { g_tile_stamps 
 extern "C" int cddmsl_last_kernel(void) { return g_last_kernel; }
 extern "C" int cddmsl_plan_only(int on) { const int was = g_plan_only; g_plan_only = on; return was; }
 
+// outputs up to CDDMSL_NT_MIN_MB MiB are stored with the default policy (their consumer may still find them in the 256 MiB last-level cache), larger
+// ones non-temporal (same-box A/B of the training step, 3 runs each: never 102.38 ms, always 101.60, above 128 MiB 101.66; on another box 100 MiB was
+// 0.4 ms ahead of always)
+static int nt_out_for(long out_bytes) {
+  static const long nt_min_mb = getenv("CDDMSL_NT_MIN_MB") ? atol(getenv("CDDMSL_NT_MIN_MB")) : 128;
+  return out_bytes > (nt_min_mb << 20) ? 1 : 0;
+}
+
 static int conv_fwd_impl(const void* x, const void* w, void* y, const float* scale, const float* bias,
                          const void* residual, const void* relu_mask, int Nimg, int Hi, int Wi, int Cin,
                          int Cout, int KH, int KW, int stride, int pad, int pool, int ldy, int ldr, int ldm,
@@ -3093,11 +3101,7 @@ static int conv_fwd_impl(const void* x, const void* w, void* y, const float* sca
   a.tstamps = g_tile_stamps;
 #endif
   if (a.M == 0) return CDDMSL_OK;
-  {               // outputs up to this many MiB are stored with the default policy (their consumer may still find them in the 256 MiB last-level cache)
-    // (same-box A/B of the training step, 3 runs each: never 102.38 ms, always 101.60, above 128 MiB 101.66; on another box 100 MiB was 0.4 ms ahead of always)
-    static const long nt_min_mb = getenv("CDDMSL_NT_MIN_MB") ? atol(getenv("CDDMSL_NT_MIN_MB")) : 128;
-    a.nt_out = (long)a.M * Cout * 2 > (nt_min_mb << 20) ? 1 : 0;
-  }
+  a.nt_out = nt_out_for((long)a.M * Cout * 2);
   if (y8) {       // e4m3 second output: bf16 launches of the 256x256 kernel only (its epilogue writes it)
     if (dtype != 0 || (out_f32 & 1) || ldy != Cout || !use_gemm256(a)) return CDDMSL_ERR_ARG;
     a.y8 = (char*)y8; a.q8 = q8; a.amax8 = (unsigned*)amax8;
@@ -3144,6 +3148,7 @@ extern "C" int cddmsl_conv_fwd_fp8(const void* x, const void* w, void* y, const 
   long M = (long)Nimg * a.Ho * a.Wo;
   if (M > 0x7fffff00L) return CDDMSL_ERR_ARG;
   a.M = (int)M; a.cpp = Cin / 16; a.Kc = KH * KW * a.cpp;
+  a.nt_out = nt_out_for(M * Cout * 2);
   a.dWo = make_fastdiv((unsigned)a.Wo); a.dHo = make_fastdiv((unsigned)a.Ho);
   a.dcpp = make_fastdiv((unsigned)a.cpp); a.dKW = make_fastdiv((unsigned)KW);
   a.xrs = a.cpp; a.wrs = a.Kc; a.bx = a.bw = a.by = 0;
