@@ -23,6 +23,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # (see cddmsl_amd/__init__.py; set before anything can initialise the HIP runtime)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -1,1 +1,7 @@
 """cddmsl_amd: MI355X-native hot path of CDDMSL."""
+import os as _os
+
+# Kernel arguments in device-visible memory (a ROCclr switch, read when the HIP runtime initialises -- i.e. at the first GPU call, which
+# comes after this import): the ~1000 dependent launches of a training step start ~1 us earlier each; measured on the step, same box, 3 runs
+# each: 97.98 -> 96.88 ms.  An explicit setting in the environment wins.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
